@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: D2Q9 BGK fused collide+stream sweep, MLUPS and fraction of the HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp64] [--scheme pull|push]
+                    [--scene shear|lid] [--nx NX] [--ny-per-gpu NY]
+
+One "step" is one time step: one pass of the sweep over the whole lattice (every node updated
+once).  N=1 runs the single-GPU HBM-roofline configuration (shear-wave decay, 16384 x 16384, fp32,
+pull streaming).  N>1 (launched by torch.distributed.run, one rank per GPU) gives every rank a
+16384 x 16384 y-slab of a 16384 x (16384*N) lattice and exchanges one halo row per slab edge per
+step over RCCL, overlapped with the interior update: weak scaling, value = all ranks' lattice
+updates per second.
+
+Inputs are resident in HBM when the clock starts (allocation and initialisation are outside the
+timed region); the timed region is bracketed by barrier + device synchronise on both sides and the
+maximum over ranks is reported.
+
+The JSON line also carries
+  roofline:     algorithmic HBM bytes of one sweep launch (72 B per node fp32, 144 B fp64: 9 reads +
+                9 writes) / the launch duration measured with HIP events on the launch stream,
+                against the 8 TB/s HBM3E peak;
+  cpu_baseline: the CPU restatement of the reference algorithm (oracle/, OpenMP over rows) timed on
+                this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--scheme", choices=["pull", "push"], default="pull")
+    ap.add_argument("--scene", choices=["shear", "lid"], default="shear")
+    ap.add_argument("--nx", type=int, default=16384)
+    ap.add_argument("--ny-per-gpu", type=int, default=16384)
+    ap.add_argument("--omega", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU-baseline sample")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange halos on the compute stream")
+    return ap.parse_args()
+
+
+def cpu_baseline(nx, rows, steps, precision, scheme, scene, omega):
+    """Time the CPU oracle (the checker, here only as a reported baseline) on a bounded sample."""
+    import numpy as np
+    from oracle import oracle as orc
+
+    dt = np.float32 if precision == "fp32" else np.float64
+    # first-touch / page-in outside the timed part
+    orc.run(scene, scheme, nx, rows, 1, omega, dt)
+    t0 = time.perf_counter()
+    orc.run(scene, scheme, nx, rows, steps, omega, dt)
+    dt_s = time.perf_counter() - t0
+    return {
+        "value": nx * rows * steps / dt_s / 1e6,
+        "unit": "MLUPS",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": f"{scene} {scheme} {precision} {nx}x{rows}, {steps} steps incl. init "
+                  f"({dt_s:.1f} s), C restatement of the reference algorithm, OpenMP over rows",
+    }
+
+
+def pmc_traffic(workload_key):
+    """Per-launch HBM traffic measured with rocprofv3 PMC passes, if a summary for exactly this
+    workload has been committed under profiles/ (bench.py cannot collect counters itself)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        return table.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from lbm_amd import Simulation, SlabSimulation
+
+    dtype = torch.float32 if args.precision == "fp32" else torch.float64
+    bytes_per_node = 72 if args.precision == "fp32" else 144
+    nx, ny_loc = args.nx, args.ny_per_gpu
+    ny_glob = ny_loc * world
+
+    if world == 1:
+        sim = Simulation(nx, ny_loc, scene=args.scene, scheme=args.scheme, dtype=dtype,
+                         omega=args.omega, device=device)
+    else:
+        sim = SlabSimulation(nx, ny_glob, scene=args.scene, scheme=args.scheme, dtype=dtype,
+                             omega=args.omega, device=device, overlap=not args.no_overlap)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    sim.step(args.warmup)
+    stream = torch.cuda.current_stream(device)  # the stream the sweeps are launched on
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    sim.step(args.steps)
+    ev1.record(stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the run must still be a physical flow (no NaN, right magnitude)
+    vmax = sim.max_velocity()
+    if not (0.0 <= vmax < 1.0):
+        raise SystemExit(f"benchmark state is not physical: max |u| = {vmax}")
+
+    if rank == 0:
+        updates = nx * ny_glob * args.steps
+        mlups = updates / elapsed / 1e6
+        # dominant kernel = the sweep; at N=1 a step is exactly one launch of it
+        launch_s = dev_ms * 1e-3 / args.steps
+        achieved = nx * ny_loc * bytes_per_node / launch_s / 1e9
+        workload = (f"{'shear-wave decay' if args.scene == 'shear' else 'lid-driven cavity'} "
+                    f"{nx}x{ny_glob} {args.precision} {args.scheme}")
+        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}"
+        out = {
+            "metric": "MLUPS",
+            "value": mlups,
+            "unit": "MLUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "scene": args.scene, "scheme": args.scheme, "nx": nx, "ny_global": ny_glob,
+                "ny_per_gpu": ny_loc, "omega": args.omega,
+                "decomposition": "single device" if world == 1 else f"{world} y-slabs, 1 halo row, RCCL send/recv",
+                "roofline_mlups_per_gpu": HBM_PEAK_GBS * 1e3 / bytes_per_node,
+                "frac_of_roofline_whole_job": mlups / (world * HBM_PEAK_GBS * 1e3 / bytes_per_node),
+                "max_velocity_after_run": vmax,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(key) if world == 1 else None,
+                "kernel": f"{args.scheme} {'periodic' if args.scene == 'shear' else 'lid-driven'} sweep",
+                "algorithmic_bytes_per_launch": nx * ny_loc * bytes_per_node,
+                "launch_ms": launch_s * 1e3,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, args.cpu_rows, args.cpu_steps, args.precision,
+                                               args.scheme, args.scene, args.omega)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/*
+ * lbm_hip.h -- C ABI of the MI355X (gfx950) D2Q9 BGK lattice-Boltzmann hot path.
+ *
+ * Every entry point replaces one free function of the reference's operator layer
+ * (reference: src/init.h, src/pull-push.h, src/io.h of JulianKarrer/lbm); the citation next to each
+ * declaration names it.  Where the reference passes Kokkos View handles, this ABI takes the raw
+ * device pointer of the same storage: populations are SoA [Q=9][NY][NX], x contiguous, element
+ * (q,y,x) at ((q*NY)+y)*NX+x (reference global.h:37-41,112 with COALESCING=true, main.cpp:37-38).
+ * Where the reference passes scalars as rank-0 device Views (global.h:121-147) this ABI takes plain
+ * values; they become kernel arguments.
+ *
+ * Conventions
+ *   - `prec` is sizeof(FLT): LBM_F32 (4) or LBM_F64 (8) -- the reference's USE_SINGLE_PRECISION
+ *     switch (global.h:21-27) made a run-time argument.
+ *   - `f` is read-only and `buf` write-only within a sweep; they must not overlap.  The caller swaps
+ *     them between steps (reference main.cpp:82-84).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All calls are
+ *     asynchronous on that stream unless the comment says the call synchronises.
+ *   - Pointers are device pointers on the current HIP device, 16-byte aligned.
+ *   - Every function returns an lbm_status; nothing throws.  lbm_last_error() gives the detail of the
+ *     calling thread's last failure.
+ *   - x is always periodic inside a *_rows call (a slab spans the full NX); the reference's
+ *     2-D halo forms (inner/outer) take explicit bounds and never wrap.
+ */
+#ifndef LBM_HIP_H
+#define LBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lbm_status {
+    LBM_OK = 0,
+    LBM_ERR_INVALID_ARGUMENT = 1, /* null/unaligned pointer, zero extent, bad precision, bad range */
+    LBM_ERR_HIP = 2,              /* a HIP runtime call failed; see lbm_last_error() */
+    LBM_ERR_NO_DEVICE = 3,        /* no usable gfx950 device */
+    LBM_ERR_UNSUPPORTED = 4
+} lbm_status;
+
+enum { LBM_F32 = 4, LBM_F64 = 8 };
+
+/* Number of discrete velocities (reference global.h:86). */
+enum { LBM_Q = 9 };
+
+const char *lbm_status_string(int status);
+const char *lbm_last_error(void);
+/* ABI version; bumped when a signature changes. */
+int lbm_abi_version(void);
+
+/* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
+ * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (multiple of 64, <=1024) and
+ * rows handled by one workgroup.  0 keeps the built-in choice. */
+int lbm_set_launch_shape(unsigned threads_x, unsigned rows_per_block);
+
+/* ---------------------------------------------------------------- initialisation ----------- */
+
+/* Replaces init_shearwave (init.h:13, init.cpp:5-34).  Rows [halo, ny-halo) of f get the
+ * equilibrium of ux = u*sinf(2*pi*(y-halo+y_below)/y_glob), uy = 0; halo is the reference's
+ * USE_MPI offset (0 or 1, init.cpp:7-12).  The per-row equilibrium table is evaluated on the host
+ * with libm sinf and double arithmetic exactly as init.cpp:57-84 spells it, then broadcast along x
+ * on the device.  Synchronises the stream. */
+int lbm_init_shearwave(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, double u,
+                       uint64_t y_below, uint64_t y_glob, unsigned halo, void *stream);
+
+/* Replaces init_rest (init.h:18, init.cpp:36-49): every row of f gets w_q*rho_init. */
+int lbm_init_rest(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, void *stream);
+
+/* ---------------------------------------------------------------- periodic sweeps ---------- */
+
+/* Replaces pull_periodic_no_mpi (pull-push.h:84, pull-push.cpp:268-288). */
+int lbm_pull_periodic_no_mpi(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
+                             double om, void *stream);
+/* Replaces push_periodic_no_mpi (pull-push.h:73, pull-push.cpp:246-266). */
+int lbm_push_periodic_no_mpi(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
+                             double om, void *stream);
+
+/* Slab forms: rows [y_lo,y_hi) of an [9][ny][nx] array, x periodic.  wrap_y != 0 wraps the y
+ * neighbours inside the array (pull-push.cpp:277-280); wrap_y == 0 reads/writes rows y-1 and y+1
+ * as they are (ghost rows present: requires y_lo >= 1 and y_hi <= ny-1), which is the y part of
+ * pull_periodic_inner / push_periodic_inner (pull-push.h:95,107). */
+int lbm_pull_periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                           uint64_t y_lo, uint64_t y_hi, int wrap_y, void *stream);
+int lbm_push_periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                           uint64_t y_lo, uint64_t y_hi, int wrap_y, void *stream);
+
+/* Replace pull_periodic_inner / push_periodic_inner (pull-push.h:95,107; pull-push.cpp:291-332):
+ * rectangle [LX,HX) x [LY,HY) of a halo'd array, no wrap (requires 1<=LX, HX<=nx-1, 1<=LY,
+ * HY<=ny-1). */
+int lbm_pull_periodic_inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t LX, uint64_t LY, uint64_t HX, uint64_t HY, void *stream);
+int lbm_push_periodic_inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t LX, uint64_t LY, uint64_t HX, uint64_t HY, void *stream);
+/* Replace pull_periodic_outer / push_periodic_outer (pull-push.h:117,126; pull-push.cpp:335-429):
+ * the ring x=1, x=nx-2, y=1, y=ny-2 of a halo'd array (requires nx,ny >= 4). */
+int lbm_pull_periodic_outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            void *stream);
+int lbm_push_periodic_outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            void *stream);
+
+/* ---------------------------------------------------------------- lid-driven cavity -------- */
+
+/* Replaces push_lid_driven (pull-push.h:140, pull-push.cpp:432-531): push sweep with half-way
+ * bounce-back on all four walls and the moving lid above y=ny-1 (df = rho_eq*u_lid/6). */
+int lbm_push_lid_driven(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                        double rho_eq, double u_lid, void *stream);
+/* Pull form of the same boundary conditions.  No counterpart in the reference (its lid scene always
+ * pushes, main.cpp:72-74); the stored state is post-collision as in pull_periodic. */
+int lbm_pull_lid_driven(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                        double rho_eq, double u_lid, void *stream);
+/* Slab forms: rows [y_lo,y_hi) of the array; array row r is global row r + y_goff of a cavity
+ * ny_glob rows high, so the bottom wall / lid act only where the global row is 0 / ny_glob-1. */
+int lbm_push_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                      double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                      uint64_t ny_glob, void *stream);
+int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                      double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                      uint64_t ny_glob, void *stream);
+
+/* ---------------------------------------------------------------- output path -------------- */
+
+/* Replaces compute_velocities (io.cpp:136-174).  vel is a device array [2][y_hi-y_lo][nx] (ux plane,
+ * then uy plane), so stores are coalesced; the reference's vel(x,y,c) indexing carries no
+ * arithmetic. */
+int lbm_compute_velocities(const void *f, void *vel, int prec, uint64_t nx, uint64_t ny,
+                           uint64_t y_lo, uint64_t y_hi, void *stream);
+/* |u| per node as the -ov output forms it (io.cpp:236-238): sqrtf of the FLT sum of squares.
+ * mag is a device array [y_hi-y_lo][nx]. */
+int lbm_velocity_magnitudes(const void *f, void *mag, int prec, uint64_t nx, uint64_t ny,
+                            uint64_t y_lo, uint64_t y_hi, void *stream);
+/* Replaces the MAX_VEL reduction of output() (io.cpp:184-208): max over rows [y_lo,y_hi) of
+ * sqrtf(ux^2+uy^2), NaNs ignored, -1e30 when no node qualifies.  The result is written as one FLT
+ * to out_dev (device memory, 8-byte aligned); asynchronous.  Uses a small per-device scratch word
+ * the library allocates on first use: two calls overlapping on one device race. */
+int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
+                         uint64_t y_lo, uint64_t y_hi, void *stream);
+/* Same, result delivered to the host as double (exact widening of the FLT value).  Synchronises the
+ * stream. */
+int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
+                     uint64_t y_hi, void *stream, double *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_HIP_H */

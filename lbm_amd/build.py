@@ -1,0 +1,58 @@
+"""In-tree build of the HIP shared library (liblbm_hip.so) for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the built library
+travels to the GPU box with the source tree.  FMA contraction is disabled on purpose: the kernels
+must round exactly where the reference's expressions round (see csrc/lbm_device.h).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "liblbm_hip.so")
+SOURCES = [os.path.join(HERE, "csrc", "lbm_capi.hip")]
+DEPS = SOURCES + [os.path.join(HERE, "csrc", "lbm_device.h"), os.path.join(ROOT, "include", "lbm_hip.h")]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",       # no a*b+c fusion: bit-parity with a strict evaluation of the reference
+    "-fno-fast-math",
+    "-fPIC",
+    "-shared",
+    "-Wall",
+    "-Wextra",
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile liblbm_hip.so if missing or older than its sources; return its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,600 @@
+// C ABI (include/lbm_hip.h) over the gfx950 kernels of lbm_device.h.
+//
+// Host-side duties only: argument validation (a faulting kernel can take the whole node down, so
+// every shape the kernels assume is checked here), choice between the 128-bit vector kernels and
+// the scalar any-size kernels, launch geometry, the host-evaluated equilibrium tables of the
+// initialisers, and error reporting.  No computation on populations happens on the host.
+#include "lbm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "lbm_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(LBM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// launch-shape hint (lbm_set_launch_shape)
+unsigned g_threads_x = 0;
+unsigned g_rows_per_block = 0;
+
+constexpr uint64_t kMaxExtent = 0x7fffffffull;  // extents are 32-bit inside the kernels
+
+int check_common(const void *f, int prec, uint64_t nx, uint64_t ny)
+{
+    if (prec != LBM_F32 && prec != LBM_F64)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "precision must be 4 (fp32) or 8 (fp64), got %d", prec);
+    if (f == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null population pointer");
+    if ((uintptr_t)f % 16 != 0)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "population pointer %p is not 16-byte aligned", f);
+    if (nx == 0 || ny == 0) return fail(LBM_ERR_INVALID_ARGUMENT, "empty lattice %llux%llu",
+                                        (unsigned long long)nx, (unsigned long long)ny);
+    if (nx > kMaxExtent || ny > kMaxExtent)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "lattice extent beyond 2^31-1: %llux%llu",
+                    (unsigned long long)nx, (unsigned long long)ny);
+    return LBM_OK;
+}
+
+int check_pair(const void *f, const void *buf, int prec, uint64_t nx, uint64_t ny)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (buf == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null write-buffer pointer");
+    if ((uintptr_t)buf % 16 != 0)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "write-buffer pointer %p is not 16-byte aligned", buf);
+    const uint64_t bytes = 9ull * nx * ny * (uint64_t)prec;
+    const uintptr_t a = (uintptr_t)f, b = (uintptr_t)buf;
+    if ((a <= b && b < a + bytes) || (b <= a && a < b + bytes))
+        return fail(LBM_ERR_INVALID_ARGUMENT, "f and buf overlap");
+    return LBM_OK;
+}
+
+int check_rows(uint64_t ny, uint64_t y_lo, uint64_t y_hi, bool needs_ghosts)
+{
+    if (y_lo > y_hi || y_hi > ny)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "row range [%llu,%llu) outside [0,%llu)",
+                    (unsigned long long)y_lo, (unsigned long long)y_hi, (unsigned long long)ny);
+    if (needs_ghosts && y_lo < y_hi && (y_lo < 1 || y_hi + 1 > ny))
+        return fail(LBM_ERR_INVALID_ARGUMENT,
+                    "row range [%llu,%llu) needs ghost rows y_lo-1 and y_hi inside [0,%llu)",
+                    (unsigned long long)y_lo, (unsigned long long)y_hi, (unsigned long long)ny);
+    return LBM_OK;
+}
+
+unsigned pick_block(uint64_t lanes_per_row)
+{
+    unsigned b = g_threads_x ? g_threads_x : 256u;
+    // do not launch workgroups much wider than a row
+    while (b > 64 && (uint64_t)b / 2 >= lanes_per_row) b /= 2;
+    return b;
+}
+
+dim3 make_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
+{
+    const unsigned rpb = g_rows_per_block ? g_rows_per_block : 1u;
+    uint64_t gy = (rows + rpb - 1) / rpb;
+    if (gy > 65535) gy = 65535;
+    if (gy == 0) gy = 1;
+    return dim3((unsigned)((lanes_per_row + block - 1) / block), (unsigned)gy, 1);
+}
+
+lbm::Geom make_geom(uint64_t nx, uint64_t ny, uint64_t y_lo, uint64_t y_hi, int wrap_y,
+                    int64_t y_goff = 0, uint64_t ny_glob = 0)
+{
+    lbm::Geom g;
+    g.nx = (uint32_t)nx;
+    g.ny = (uint32_t)ny;
+    g.y_lo = (uint32_t)y_lo;
+    g.y_hi = (uint32_t)y_hi;
+    g.wrap_y = wrap_y;
+    g.y_goff = y_goff;
+    g.ny_glob = ny_glob;
+    return g;
+}
+
+int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LBM_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return LBM_OK;
+}
+
+// Dispatch a kernel template over the supported workgroup widths.
+#define LBM_FOR_BLOCK(block, ...)                         \
+    switch (block) {                                      \
+        case 64:  { constexpr int B = 64;  __VA_ARGS__; } break;  \
+        case 128: { constexpr int B = 128; __VA_ARGS__; } break;  \
+        case 512: { constexpr int B = 512; __VA_ARGS__; } break;  \
+        default:  { constexpr int B = 256; __VA_ARGS__; } break;  \
+    }
+
+template <typename T> constexpr int vec_width() { return 16 / (int)sizeof(T); }
+
+// ---- periodic sweeps -------------------------------------------------------------------
+template <typename T, bool PULL>
+int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_,
+                        uint64_t y_lo, uint64_t y_hi, int wrap_y, hipStream_t stream)
+{
+    if (y_lo == y_hi) return LBM_OK;
+    const T *f = (const T *)f_;
+    T *buf = (T *)buf_;
+    const T om = (T)om_;  // reference io.cpp:112
+    constexpr int V = vec_width<T>();
+    const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, wrap_y);
+    const uint64_t rows = y_hi - y_lo;
+    if (nx % V == 0 && nx >= 2 * V) {
+        const uint64_t lanes = nx / V;
+        const unsigned block = pick_block(lanes);
+        const dim3 grid = make_grid(lanes, block, rows);
+        LBM_FOR_BLOCK(block,
+            if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), 0, stream, f, buf, g, om);
+            else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), 0, stream, f, buf, g, om))
+    } else {
+        const unsigned block = pick_block(nx);
+        const dim3 grid = make_grid(nx, block, rows);
+        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
+                               0u, (uint32_t)nx, 1, om, (T)0))
+    }
+    return launch_status(PULL ? "pull periodic" : "push periodic");
+}
+
+template <bool PULL>
+int periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                  uint64_t y_lo, uint64_t y_hi, int wrap_y, void *stream)
+{
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, !wrap_y)) return s;
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32
+               ? sweep_periodic_rows<float, PULL>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, st)
+               : sweep_periodic_rows<double, PULL>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, st);
+}
+
+// ---- halo'd 2-D forms --------------------------------------------------------------------
+template <typename T, bool PULL>
+int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, uint64_t LX,
+                uint64_t LY, uint64_t HX, uint64_t HY, hipStream_t stream)
+{
+    if (LX >= HX || LY >= HY) return LBM_OK;
+    const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
+    const unsigned block = pick_block(HX - LX);
+    const dim3 grid = make_grid(HX - LX, block, HY - LY);
+    constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
+    LBM_FOR_BLOCK(block,
+        hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, (const T *)f_,
+                           (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
+    return launch_status("periodic inner");
+}
+
+template <bool PULL>
+int inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, uint64_t LX,
+          uint64_t LY, uint64_t HX, uint64_t HY, void *stream)
+{
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (HX > nx || HY > ny || LX > HX || LY > HY)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "rectangle [%llu,%llu)x[%llu,%llu) outside %llux%llu",
+                    (unsigned long long)LX, (unsigned long long)HX, (unsigned long long)LY,
+                    (unsigned long long)HY, (unsigned long long)nx, (unsigned long long)ny);
+    if (LX < HX && LY < HY && (LX < 1 || HX + 1 > nx || LY < 1 || HY + 1 > ny))
+        return fail(LBM_ERR_INVALID_ARGUMENT, "inner rectangle needs a halo of one node on every side");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? sweep_inner<float, PULL>(f, buf, nx, ny, om, LX, LY, HX, HY, st)
+                           : sweep_inner<double, PULL>(f, buf, nx, ny, om, LX, LY, HX, HY, st);
+}
+
+template <typename T, bool PULL>
+int sweep_outer(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, hipStream_t stream)
+{
+    const uint64_t lanes = (nx - 2) + (ny - 4);
+    constexpr int B = 256;
+    hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
+                       stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
+    return launch_status("periodic outer");
+}
+
+template <bool PULL>
+int outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
+{
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (nx < 4 || ny < 4)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "outer ring needs nx,ny >= 4 (got %llux%llu)",
+                    (unsigned long long)nx, (unsigned long long)ny);
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? sweep_outer<float, PULL>(f, buf, nx, ny, om, st)
+                           : sweep_outer<double, PULL>(f, buf, nx, ny, om, st);
+}
+
+// ---- lid-driven cavity ---------------------------------------------------------------------
+template <typename T, bool PULL>
+int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_,
+                   double u_, uint64_t y_lo, uint64_t y_hi, int64_t y_goff, uint64_t ny_glob,
+                   hipStream_t stream)
+{
+    if (y_lo == y_hi) return LBM_OK;
+    const T *f = (const T *)f_;
+    T *buf = (T *)buf_;
+    const T om = (T)om_;
+    // df = RHO_EQ * U_LID / 6 in FLT (pull-push.cpp:516-518)
+    const T rho = (T)rho_, u = (T)u_;
+    const T df = rho * u / (T)6.;
+    constexpr int V = vec_width<T>();
+    const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, 0, y_goff, ny_glob);
+    const uint64_t rows = y_hi - y_lo;
+    if (nx % V == 0 && nx >= 2 * V) {
+        const uint64_t lanes = nx / V;
+        const unsigned block = pick_block(lanes);
+        const dim3 grid = make_grid(lanes, block, rows);
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), 0, stream, f, buf, g, om, df))
+    } else {
+        const unsigned block = pick_block(nx);
+        const dim3 grid = make_grid(nx, block, rows);
+        constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
+                               0u, (uint32_t)nx, 0, om, df))
+    }
+    return launch_status(PULL ? "pull lid-driven" : "push lid-driven");
+}
+
+template <bool PULL>
+int lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, double rho_eq,
+             double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff, uint64_t ny_glob,
+             void *stream)
+{
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (y_lo < y_hi) {
+        // every updated row must lie inside the cavity, and rows that are not wall rows need their
+        // y neighbours inside the array
+        const int64_t g_lo = (int64_t)y_lo + y_goff, g_hi = (int64_t)y_hi + y_goff;
+        if (ny_glob == 0 || ny_glob > kMaxExtent || g_lo < 0 || (uint64_t)g_hi > ny_glob)
+            return fail(LBM_ERR_INVALID_ARGUMENT,
+                        "rows [%llu,%llu) + offset %lld leave the cavity of height %llu",
+                        (unsigned long long)y_lo, (unsigned long long)y_hi, (long long)y_goff,
+                        (unsigned long long)ny_glob);
+        if ((g_lo != 0 && y_lo == 0) || ((uint64_t)g_hi != ny_glob && y_hi == ny))
+            return fail(LBM_ERR_INVALID_ARGUMENT,
+                        "slab rows that are not wall rows need a ghost row inside the array");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32
+               ? sweep_lid_rows<float, PULL>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, st)
+               : sweep_lid_rows<double, PULL>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, st);
+}
+
+// ---- initialisation --------------------------------------------------------------------
+// f_eq of init.cpp:57-84, evaluated on the host.  The bracket is double even for T=float because
+// the reference writes 9./2. and 3./2. (init.cpp:81-82); 1+3*cu, cu*cu and u_2 are formed in T.
+template <typename T>
+T f_eq_host(T ux, T uy, T rho_i, unsigned dir)
+{
+    static const T w[9] = {(T)(4. / 9.),  (T)(1. / 9.),  (T)(1. / 9.),  (T)(1. / 9.), (T)(1. / 9.),
+                           (T)(1. / 36.), (T)(1. / 36.), (T)(1. / 36.), (T)(1. / 36.)};
+    static const T cx[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
+    static const T cy[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+    const T cx_ux = cx[dir] * ux;
+    const T cy_uy = cy[dir] * uy;
+    const T c_i_u_r = cx_ux + cy_uy;
+    const T u_2 = ux * ux + uy * uy;
+    const T a = T(1) + T(3) * c_i_u_r;
+    const T cc = c_i_u_r * c_i_u_r;
+    const double bracket = ((double)a + 9. / 2. * (double)cc) - 3. / 2. * (double)u_2;
+    const T wr = w[dir] * rho_i;
+    return (T)((double)wr * bracket);
+}
+
+template <typename T>
+int fill_from_table(void *f_, uint64_t nx, uint64_t ny, uint64_t y_first, const std::vector<T> &table,
+                    uint64_t rows, hipStream_t stream)
+{
+    if (rows == 0) return LBM_OK;
+    T *d_table = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_table, table.size() * sizeof(T)));
+    hipError_t e = hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const unsigned block = pick_block(nx);
+        const dim3 grid = make_grid(nx, block, rows);
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_fill_rows<T, B>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
+                               (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table))
+        e = hipGetLastError();
+    }
+    // the table (host vector and device copy) must outlive the kernel
+    hipError_t e2 = hipStreamSynchronize(stream);
+    hipError_t e3 = hipFree(d_table);
+    if (e != hipSuccess) return fail(LBM_ERR_HIP, "initialisation failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(LBM_ERR_HIP, "initialisation failed: %s", hipGetErrorString(e2));
+    if (e3 != hipSuccess) return fail(LBM_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e3));
+    return LBM_OK;
+}
+
+template <typename T>
+int init_shearwave_t(void *f, uint64_t nx, uint64_t ny, double rho_, double u_, uint64_t y_below,
+                     uint64_t y_glob, unsigned halo, hipStream_t stream)
+{
+    const uint64_t rows = ny - 2ull * halo;
+    const T rho_i = (T)rho_, u_init = (T)u_;  // io.cpp:113-114
+    std::vector<T> table(9 * rows);
+    for (uint64_t r = 0; r < rows; ++r) {
+        // init.cpp:22-26 with y = r + halo: (y - use_mpi + y_below) in unsigned arithmetic
+        const uint64_t y = r + halo;
+        const T y_scaled = ((T)(y - (uint64_t)halo + y_below)) / ((T)y_glob);
+        const T ux = u_init * sinf((float)(2.0 * M_PI * y_scaled));
+        for (unsigned dir = 0; dir < 9; ++dir) table[dir * rows + r] = f_eq_host<T>(ux, (T)0., rho_i, dir);
+    }
+    return fill_from_table<T>(f, nx, ny, halo, table, rows, stream);
+}
+
+template <typename T>
+int init_rest_t(void *f, uint64_t nx, uint64_t ny, double rho_, hipStream_t stream)
+{
+    const T rho_i = (T)rho_;
+    std::vector<T> table(9 * ny);
+    for (unsigned dir = 0; dir < 9; ++dir) {
+        const T v = f_eq_host<T>((T)0., (T)0., rho_i, dir);
+        for (uint64_t r = 0; r < ny; ++r) table[dir * ny + r] = v;
+    }
+    return fill_from_table<T>(f, nx, ny, 0, table, ny, stream);
+}
+
+// ---- output path -----------------------------------------------------------------------
+template <typename T, int WHAT>
+int velocity_t(const void *f, void *out, uint64_t nx, uint64_t ny, uint64_t y_lo, uint64_t y_hi,
+               hipStream_t stream)
+{
+    if (y_lo == y_hi) return LBM_OK;
+    const unsigned block = pick_block(nx);
+    const dim3 grid = make_grid(nx, block, y_hi - y_lo);
+    LBM_FOR_BLOCK(block,
+        hipLaunchKernelGGL((lbm::k_velocity<T, WHAT, B>), grid, dim3(B), 0, stream, (const T *)f, (T *)out,
+                           (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi))
+    return launch_status("compute velocities");
+}
+
+// per-device scratch for the max-|u| key (one 256-byte line each), allocated on first use
+constexpr int kMaxDevices = 64;
+uint32_t *g_key[kMaxDevices] = {};
+std::mutex g_key_mutex;
+
+int key_scratch(uint32_t **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(LBM_ERR_NO_DEVICE, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_key_mutex);
+    if (g_key[dev] == nullptr) HIP_TRY(hipMalloc((void **)&g_key[dev], 256));
+    *out = g_key[dev];
+    return LBM_OK;
+}
+
+template <typename T>
+int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint64_t y_lo,
+                   uint64_t y_hi, hipStream_t stream)
+{
+    uint32_t *key = nullptr;
+    if (int s = key_scratch(&key)) return s;
+    HIP_TRY(hipMemsetAsync(key, 0, sizeof(uint32_t), stream));
+    if (y_lo < y_hi) {
+        constexpr int B = 256;
+        constexpr int V = vec_width<T>();
+        const uint64_t rows = y_hi - y_lo;
+        if (nx % V == 0) {
+            const uint64_t lanes = nx / V;
+            uint64_t gx = (lanes + B - 1) / B;
+            if (gx > 64) gx = 64;
+            uint64_t gy = rows < 1024 ? rows : 1024;
+            hipLaunchKernelGGL((lbm::k_max_speed<T, V, B>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
+                               (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
+        } else {
+            uint64_t gx = (nx + B - 1) / B;
+            if (gx > 64) gx = 64;
+            uint64_t gy = rows < 1024 ? rows : 1024;
+            hipLaunchKernelGGL((lbm::k_max_speed<T, 1, B>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
+                               (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
+        }
+        if (int s = launch_status("find max velocity")) return s;
+    }
+    hipLaunchKernelGGL((lbm::k_max_speed_finish<T>), dim3(1), dim3(1), 0, stream, (const uint32_t *)key, (T *)out_dev);
+    return launch_status("max velocity finish");
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+const char *lbm_status_string(int status)
+{
+    switch (status) {
+        case LBM_OK: return "ok";
+        case LBM_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case LBM_ERR_HIP: return "HIP runtime error";
+        case LBM_ERR_NO_DEVICE: return "no usable device";
+        case LBM_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char *lbm_last_error(void) { return g_err; }
+
+int lbm_abi_version(void) { return 1; }
+
+int lbm_set_launch_shape(unsigned threads_x, unsigned rows_per_block)
+{
+    if (threads_x != 0 && threads_x != 64 && threads_x != 128 && threads_x != 256 && threads_x != 512)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "threads_x must be 0, 64, 128, 256 or 512 (got %u)", threads_x);
+    g_threads_x = threads_x;
+    g_rows_per_block = rows_per_block;
+    return LBM_OK;
+}
+
+int lbm_init_shearwave(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, double u,
+                       uint64_t y_below, uint64_t y_glob, unsigned halo, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (halo > 1) return fail(LBM_ERR_INVALID_ARGUMENT, "halo must be 0 or 1 (got %u)", halo);
+    if (ny < 2ull * halo) return fail(LBM_ERR_INVALID_ARGUMENT, "ny=%llu too small for halo", (unsigned long long)ny);
+    if (y_glob == 0) return fail(LBM_ERR_INVALID_ARGUMENT, "y_glob must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? init_shearwave_t<float>(f, nx, ny, rho_init, u, y_below, y_glob, halo, st)
+                           : init_shearwave_t<double>(f, nx, ny, rho_init, u, y_below, y_glob, halo, st);
+}
+
+int lbm_init_rest(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? init_rest_t<float>(f, nx, ny, rho_init, st)
+                           : init_rest_t<double>(f, nx, ny, rho_init, st);
+}
+
+int lbm_pull_periodic_no_mpi(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
+{
+    return periodic_rows<true>(f, buf, prec, nx, ny, om, 0, ny, 1, stream);
+}
+int lbm_push_periodic_no_mpi(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
+{
+    return periodic_rows<false>(f, buf, prec, nx, ny, om, 0, ny, 1, stream);
+}
+int lbm_pull_periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                           uint64_t y_lo, uint64_t y_hi, int wrap_y, void *stream)
+{
+    return periodic_rows<true>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+}
+int lbm_push_periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                           uint64_t y_lo, uint64_t y_hi, int wrap_y, void *stream)
+{
+    return periodic_rows<false>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+}
+int lbm_pull_periodic_inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t LX, uint64_t LY, uint64_t HX, uint64_t HY, void *stream)
+{
+    return inner<true>(f, buf, prec, nx, ny, om, LX, LY, HX, HY, stream);
+}
+int lbm_push_periodic_inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t LX, uint64_t LY, uint64_t HX, uint64_t HY, void *stream)
+{
+    return inner<false>(f, buf, prec, nx, ny, om, LX, LY, HX, HY, stream);
+}
+int lbm_pull_periodic_outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
+{
+    return outer<true>(f, buf, prec, nx, ny, om, stream);
+}
+int lbm_push_periodic_outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
+{
+    return outer<false>(f, buf, prec, nx, ny, om, stream);
+}
+
+int lbm_push_lid_driven(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                        double rho_eq, double u_lid, void *stream)
+{
+    return lid_rows<false>(f, buf, prec, nx, ny, om, rho_eq, u_lid, 0, ny, 0, ny, stream);
+}
+int lbm_pull_lid_driven(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                        double rho_eq, double u_lid, void *stream)
+{
+    return lid_rows<true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, 0, ny, 0, ny, stream);
+}
+int lbm_push_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                      double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                      uint64_t ny_glob, void *stream)
+{
+    return lid_rows<false>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
+}
+int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                      double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                      uint64_t ny_glob, void *stream)
+{
+    return lid_rows<true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
+}
+
+int lbm_compute_velocities(const void *f, void *vel, int prec, uint64_t nx, uint64_t ny,
+                           uint64_t y_lo, uint64_t y_hi, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (vel == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null velocity pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? velocity_t<float, 0>(f, vel, nx, ny, y_lo, y_hi, st)
+                           : velocity_t<double, 0>(f, vel, nx, ny, y_lo, y_hi, st);
+}
+
+int lbm_velocity_magnitudes(const void *f, void *mag, int prec, uint64_t nx, uint64_t ny,
+                            uint64_t y_lo, uint64_t y_hi, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (mag == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null magnitude pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? velocity_t<float, 1>(f, mag, nx, ny, y_lo, y_hi, st)
+                           : velocity_t<double, 1>(f, mag, nx, ny, y_lo, y_hi, st);
+}
+
+int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
+                         uint64_t y_lo, uint64_t y_hi, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (out_dev == nullptr || (uintptr_t)out_dev % 8 != 0)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "result pointer must be non-null and 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, st)
+                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, st);
+}
+
+int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
+                     uint64_t y_hi, void *stream, double *out_host)
+{
+    if (out_host == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null result pointer");
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    uint32_t *key = nullptr;
+    if (int s = key_scratch(&key)) return s;
+    // the decoded value goes to the second half of the scratch line
+    void *res = (void *)((char *)key + 128);
+    hipStream_t st = (hipStream_t)stream;
+    int s = prec == LBM_F32 ? max_velocity_t<float>(f, res, nx, ny, y_lo, y_hi, st)
+                            : max_velocity_t<double>(f, res, nx, ny, y_lo, y_hi, st);
+    if (s) return s;
+    double host = 0;
+    HIP_TRY(hipMemcpyAsync(&host, res, (size_t)prec, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (prec == LBM_F32) {
+        float v;
+        memcpy(&v, &host, sizeof v);
+        *out_host = (double)v;
+    } else {
+        *out_host = host;
+    }
+    return LBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,605 @@
+// Device code of the D2Q9 BGK collide-and-stream path for gfx950 (MI355X, wave64).
+//
+// Design: the sweep is a pure HBM stream -- every population is read exactly once and written
+// exactly once per step (9 reads + 9 writes per node, ~110 flops) -- so the kernels are shaped
+// around memory instructions, not arithmetic:
+//   * SoA [9][NY][NX]; one lane owns V consecutive x of one row, V*sizeof(T) = 16 bytes, so every
+//     access is a 128-bit global_load/store_dwordx4 and a wave moves 1 KiB per instruction;
+//   * the three "x-1" and three "x+1" channels are fetched (pull) or written (push) with 4-byte
+//     aligned 128-bit accesses, shifted by one element; only the first and last lane of a row take
+//     the element-wise wrap path;
+//   * row base addresses are wave-uniform (SGPR), the per-lane part is one 32-bit x offset;
+//   * all scalars (nx, ny, omega, ...) are kernel arguments;
+//   * arithmetic follows the reference's expression trees with FMA contraction off, so results
+//     are bit-identical to a strict IEEE evaluation of the reference source.
+//
+// Reference citations are to JulianKarrer/lbm src/ (pull-push.cpp, init.cpp, io.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace lbm {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------
+// 128-bit vector access helpers.  VecA: naturally aligned; VecU: element aligned (shifted rows).
+template <typename T, int V>
+struct VecTypes {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    typedef vec_t vec_a __attribute__((aligned(sizeof(T) * V)));
+    typedef vec_t vec_u __attribute__((aligned(sizeof(T))));
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_a(T (&r)[V], const T *p)
+{
+    typename VecTypes<T, V>::vec_t v = *reinterpret_cast<const typename VecTypes<T, V>::vec_a *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = v[i];
+}
+template <typename T, int V>
+__device__ __forceinline__ void load_u(T (&r)[V], const T *p)
+{
+    typename VecTypes<T, V>::vec_t v = *reinterpret_cast<const typename VecTypes<T, V>::vec_u *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = v[i];
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_a(T *p, const T (&r)[V])
+{
+    typename VecTypes<T, V>::vec_t v;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = r[i];
+    *reinterpret_cast<typename VecTypes<T, V>::vec_a *>(p) = v;
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_u(T *p, const T (&r)[V])
+{
+    typename VecTypes<T, V>::vec_t v;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = r[i];
+    *reinterpret_cast<typename VecTypes<T, V>::vec_u *>(p) = v;
+}
+
+// r[i] = row[(x0 + i - 1) mod nx]   (values arriving from the left neighbour, periodic in x)
+template <typename T, int V>
+__device__ __forceinline__ void load_from_left(T (&r)[V], const T *row, uint32_t x0, uint32_t nx)
+{
+    if (x0 != 0) {
+        load_u<T, V>(r, row + (x0 - 1));
+    } else {
+        r[0] = row[nx - 1];
+#pragma unroll
+        for (int i = 1; i < V; ++i) r[i] = row[i - 1];
+    }
+}
+// r[i] = row[(x0 + i + 1) mod nx]   (values arriving from the right neighbour)
+template <typename T, int V>
+__device__ __forceinline__ void load_from_right(T (&r)[V], const T *row, uint32_t x0, uint32_t nx)
+{
+    if (x0 + V != nx) {
+        load_u<T, V>(r, row + (x0 + 1));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V - 1; ++i) r[i] = row[x0 + 1 + i];
+        r[V - 1] = row[0];
+    }
+}
+// row[(x0 + i + 1) mod nx] = r[i]   (values leaving to the right neighbour)
+template <typename T, int V>
+__device__ __forceinline__ void store_to_right(T *row, uint32_t x0, uint32_t nx, const T (&r)[V])
+{
+    if (x0 + V != nx) {
+        store_u<T, V>(row + (x0 + 1), r);
+    } else {
+#pragma unroll
+        for (int i = 0; i < V - 1; ++i) row[x0 + 1 + i] = r[i];
+        row[0] = r[V - 1];
+    }
+}
+// row[(x0 + i - 1) mod nx] = r[i]   (values leaving to the left neighbour)
+template <typename T, int V>
+__device__ __forceinline__ void store_to_left(T *row, uint32_t x0, uint32_t nx, const T (&r)[V])
+{
+    if (x0 != 0) {
+        store_u<T, V>(row + (x0 - 1), r);
+    } else {
+        row[nx - 1] = r[0];
+#pragma unroll
+        for (int i = 1; i < V; ++i) row[i - 1] = r[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BGK relaxation of one node.  Expression trees as in pull-push.cpp:25-72 (pull), :138-185
+// (push), :454-483 (lid): rho summed left to right, one division, shared sub-expressions
+// f45*s*s = (f45*s)*s, bracket ((1 -+ 3a) + a2) - usq, out = f + om*((w*bracket) - f).
+// Constants are rounded once from double (pull-push.cpp:39-43).
+template <typename T>
+__device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, const T f_3,
+                                        const T f_4, const T f_5, const T f_6, const T f_7,
+                                        const T f_8, const T om, T (&o)[9])
+{
+    const T rho = f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8;
+    const T rho_inv = T(1.0) / rho;
+    const T ux = (f_1 - f_3 + f_5 - f_6 - f_7 + f_8) * rho_inv;
+    const T uy = (f_2 - f_4 + f_5 + f_6 - f_7 - f_8) * rho_inv;
+    const T f45 = T(4.5), f15 = T(1.5);
+    const T f49 = T(4. / 9.), f19 = T(1. / 9.), f136 = T(1. / 36.);
+    const T one = T(1), three = T(3);
+    const T w_1_36 = rho * f136;
+    const T w_1_9 = rho * f19;
+    const T w_4_9 = rho * f49;
+    const T uxpuy = ux + uy;
+    const T uxpuy_2 = f45 * uxpuy * uxpuy;
+    const T uymux = uy - ux;
+    const T uymux_2 = f45 * uymux * uymux;
+    const T ux_2 = f45 * ux * ux;
+    const T uy_2 = f45 * uy * uy;
+    const T usq = f15 * (ux * ux + uy * uy);
+    o[7] = f_7 + om * ((w_1_36 * (one - three * uxpuy + uxpuy_2 - usq)) - f_7);
+    o[4] = f_4 + om * ((w_1_9 * (one - three * uy + uy_2 - usq)) - f_4);
+    o[8] = f_8 + om * ((w_1_36 * (one - three * uymux + uymux_2 - usq)) - f_8);
+    o[3] = f_3 + om * ((w_1_9 * (one - three * ux + ux_2 - usq)) - f_3);
+    o[0] = f_0 + om * ((w_4_9 * (one - usq)) - f_0);
+    o[1] = f_1 + om * ((w_1_9 * (one + three * ux + ux_2 - usq)) - f_1);
+    o[6] = f_6 + om * ((w_1_36 * (one + three * uymux + uymux_2 - usq)) - f_6);
+    o[2] = f_2 + om * ((w_1_9 * (one + three * uy + uy_2 - usq)) - f_2);
+    o[5] = f_5 + om * ((w_1_36 * (one + three * uxpuy + uxpuy_2 - usq)) - f_5);
+}
+
+// Macroscopic velocity of one node as io.cpp:143-171 and io.cpp:190-202 form it (the two sites
+// give identical values: (sum)*rho_inv).
+template <typename T>
+__device__ __forceinline__ void node_velocity(const T f_0, const T f_1, const T f_2, const T f_3,
+                                              const T f_4, const T f_5, const T f_6, const T f_7,
+                                              const T f_8, T &ux, T &uy)
+{
+    const T sx = f_1 - f_3 + f_5 - f_6 - f_7 + f_8;
+    const T sy = f_2 - f_4 + f_5 + f_6 - f_7 - f_8;
+    const T rho_inv = T(1.0) / (f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8);
+    ux = sx * rho_inv;
+    uy = sy * rho_inv;
+}
+// |u| as io.cpp:204 / :238: SQRT is sqrtf for both precisions (global.h:30).
+template <typename T>
+__device__ __forceinline__ T node_speed(const T ux, const T uy)
+{
+    return (T)sqrtf((float)(ux * ux + uy * uy));
+}
+
+// ------------------------------------------------------------------------------------------
+// Geometry shared by all sweeps.  Array is [9][ny][nx]; plane = ny*nx elements.
+struct Geom {
+    uint32_t nx;      // row length
+    uint32_t ny;      // rows in the array (incl. ghost rows if any)
+    uint32_t y_lo;    // first row to update
+    uint32_t y_hi;    // one past the last row to update
+    int wrap_y;       // periodic y inside the array
+    // lid scenes: global row = row + y_goff, cavity height ny_glob
+    int64_t y_goff;
+    uint64_t ny_glob;
+};
+
+template <typename T>
+__device__ __forceinline__ const T *rowp(const T *base, size_t plane, int q, uint32_t y, uint32_t nx)
+{
+    return base + ((size_t)q * plane + (size_t)y * nx);
+}
+template <typename T>
+__device__ __forceinline__ T *rowp(T *base, size_t plane, int q, uint32_t y, uint32_t nx)
+{
+    return base + ((size_t)q * plane + (size_t)y * nx);
+}
+
+__device__ __forceinline__ uint32_t row_up(const Geom &g, uint32_t y)
+{
+    return g.wrap_y ? ((y + 1 == g.ny) ? 0u : y + 1) : y + 1;
+}
+__device__ __forceinline__ uint32_t row_down(const Geom &g, uint32_t y)
+{
+    return g.wrap_y ? ((y == 0) ? g.ny - 1 : y - 1) : y - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// PERIODIC PULL, vector form.  Replaces the "pull periodic" dispatch (pull-push.cpp:268-288) and
+// its device function pull_periodic (:5-73).  Grid: x = 16-byte chunks of a row, y = rows
+// (strided).  Requires nx % V == 0, nx >= 2V.
+template <typename T, int V, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
+{
+    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx) return;
+    const size_t plane = (size_t)g.ny * g.nx;
+    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+        const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+        T c0[V], c1[V], c2[V], c3[V], c4[V], c5[V], c6[V], c7[V], c8[V];
+        // gather: pull-push.cpp:13-21
+        load_from_right<T, V>(c7, rowp(f, plane, 7, yu, g.nx), x0, g.nx);
+        load_a<T, V>(c4, rowp(f, plane, 4, yu, g.nx) + x0);
+        load_from_left<T, V>(c8, rowp(f, plane, 8, yu, g.nx), x0, g.nx);
+        load_from_right<T, V>(c3, rowp(f, plane, 3, y, g.nx), x0, g.nx);
+        load_a<T, V>(c0, rowp(f, plane, 0, y, g.nx) + x0);
+        load_from_left<T, V>(c1, rowp(f, plane, 1, y, g.nx), x0, g.nx);
+        load_from_right<T, V>(c6, rowp(f, plane, 6, yd, g.nx), x0, g.nx);
+        load_a<T, V>(c2, rowp(f, plane, 2, yd, g.nx) + x0);
+        load_from_left<T, V>(c5, rowp(f, plane, 5, yd, g.nx), x0, g.nx);
+        T o[9][V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            T r[9];
+            collide<T>(c0[i], c1[i], c2[i], c3[i], c4[i], c5[i], c6[i], c7[i], c8[i], om, r);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
+    }
+}
+
+// PERIODIC PUSH, vector form.  Replaces "push periodic" (pull-push.cpp:246-266) and push_periodic
+// (:124-186): aligned reads of the node's own nine populations, shifted writes.
+template <typename T, int V, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
+{
+    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx) return;
+    const size_t plane = (size_t)g.ny * g.nx;
+    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+        const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+        T c[9][V];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
+        T o[9][V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            T r[9];
+            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+                       c[8][i], om, r);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+        }
+        // scatter: pull-push.cpp:175-185
+        store_to_left<T, V>(rowp(buf, plane, 7, yd, g.nx), x0, g.nx, o[7]);
+        store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
+        store_to_right<T, V>(rowp(buf, plane, 8, yd, g.nx), x0, g.nx, o[8]);
+        store_to_left<T, V>(rowp(buf, plane, 3, y, g.nx), x0, g.nx, o[3]);
+        store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
+        store_to_right<T, V>(rowp(buf, plane, 1, y, g.nx), x0, g.nx, o[1]);
+        store_to_left<T, V>(rowp(buf, plane, 6, yu, g.nx), x0, g.nx, o[6]);
+        store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
+        store_to_right<T, V>(rowp(buf, plane, 5, yu, g.nx), x0, g.nx, o[5]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-node forms (any nx, explicit neighbour indices).  Used by the scalar kernels, by the
+// halo'd inner/outer forms and by the wall lanes of the lid kernels.
+template <typename T>
+__device__ __forceinline__ void pull_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
+                                          uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
+                                          uint32_t xr, uint32_t yd, uint32_t yu, T om)
+{
+    const T f_7 = rowp(f, plane, 7, yu, nx)[xr];
+    const T f_4 = rowp(f, plane, 4, yu, nx)[x];
+    const T f_8 = rowp(f, plane, 8, yu, nx)[xl];
+    const T f_3 = rowp(f, plane, 3, y, nx)[xr];
+    const T f_0 = rowp(f, plane, 0, y, nx)[x];
+    const T f_1 = rowp(f, plane, 1, y, nx)[xl];
+    const T f_6 = rowp(f, plane, 6, yd, nx)[xr];
+    const T f_2 = rowp(f, plane, 2, yd, nx)[x];
+    const T f_5 = rowp(f, plane, 5, yd, nx)[xl];
+    T o[9];
+    collide<T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) rowp(buf, plane, q, y, nx)[x] = o[q];
+}
+
+template <typename T>
+__device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
+                                          uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
+                                          uint32_t xr, uint32_t yd, uint32_t yu, T om)
+{
+    T c[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
+    T o[9];
+    collide<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
+    rowp(buf, plane, 7, yd, nx)[xl] = o[7];
+    rowp(buf, plane, 4, yd, nx)[x] = o[4];
+    rowp(buf, plane, 8, yd, nx)[xr] = o[8];
+    rowp(buf, plane, 3, y, nx)[xl] = o[3];
+    rowp(buf, plane, 0, y, nx)[x] = o[0];
+    rowp(buf, plane, 1, y, nx)[xr] = o[1];
+    rowp(buf, plane, 6, yu, nx)[xl] = o[6];
+    rowp(buf, plane, 2, yu, nx)[x] = o[2];
+    rowp(buf, plane, 5, yu, nx)[xr] = o[5];
+}
+
+// One node of push_lid_driven: pull-push.cpp:436-528.  l/r/t/b: the node touches the left /
+// right / top (lid) / bottom wall.  df = rho_eq*u_lid/6 (:518), applied only where t.
+template <typename T>
+__device__ __forceinline__ void lid_push_node(const T *__restrict__ f, T *__restrict__ buf,
+                                              size_t plane, uint32_t nx, uint32_t x, uint32_t y,
+                                              bool l, bool r, bool t, bool b, T om, T df_lid)
+{
+    T c[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
+    T o[9];
+    collide<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
+    const bool lb = l || b, lt = l || t, rb = r || b, rt = r || t;
+    const uint32_t xl = l ? x : x - 1, xr = r ? x : x + 1;
+    const uint32_t yu = t ? y : y + 1, yd = b ? y : y - 1;
+    const T df = t ? df_lid : T(0.);
+    rowp(buf, plane, lb ? 5 : 7, lb ? y : yd, nx)[lb ? x : xl] = o[7];
+    rowp(buf, plane, l ? 1 : 3, y, nx)[xl] = o[3];
+    rowp(buf, plane, lt ? 8 : 6, lt ? y : yu, nx)[lt ? x : xl] = o[6] + df;
+    rowp(buf, plane, b ? 2 : 4, yd, nx)[x] = o[4];
+    rowp(buf, plane, 0, y, nx)[x] = o[0];
+    rowp(buf, plane, t ? 4 : 2, yu, nx)[x] = o[2];
+    rowp(buf, plane, rb ? 6 : 8, rb ? y : yd, nx)[rb ? x : xr] = o[8];
+    rowp(buf, plane, r ? 3 : 1, y, nx)[xr] = o[1];
+    rowp(buf, plane, rt ? 7 : 5, rt ? y : yu, nx)[rt ? x : xr] = o[5] - df;
+}
+
+// One node of the lid-driven cavity in pull form: the store map of pull-push.cpp:520-528 read from
+// the destination side (no reference counterpart).  A population whose upstream node lies behind
+// a wall is the node's own opposite population; the two that bounce off the lid carry -+df.
+template <typename T>
+__device__ __forceinline__ void lid_pull_node(const T *__restrict__ f, T *__restrict__ buf,
+                                              size_t plane, uint32_t nx, uint32_t x, uint32_t y,
+                                              bool l, bool r, bool t, bool b, T om, T df_lid)
+{
+    const T df = t ? df_lid : T(0.);
+    const T f_0 = rowp(f, plane, 0, y, nx)[x];
+    const T f_1 = l ? rowp(f, plane, 3, y, nx)[x] : rowp(f, plane, 1, y, nx)[x - 1];
+    const T f_3 = r ? rowp(f, plane, 1, y, nx)[x] : rowp(f, plane, 3, y, nx)[x + 1];
+    const T f_2 = b ? rowp(f, plane, 4, y, nx)[x] : rowp(f, plane, 2, y - 1, nx)[x];
+    const T f_4 = t ? rowp(f, plane, 2, y, nx)[x] : rowp(f, plane, 4, y + 1, nx)[x];
+    const T f_5 = (l || b) ? rowp(f, plane, 7, y, nx)[x] : rowp(f, plane, 5, y - 1, nx)[x - 1];
+    const T f_6 = (r || b) ? rowp(f, plane, 8, y, nx)[x] : rowp(f, plane, 6, y - 1, nx)[x + 1];
+    const T f_7 = (r || t) ? (rowp(f, plane, 5, y, nx)[x] - df) : rowp(f, plane, 7, y + 1, nx)[x + 1];
+    const T f_8 = (l || t) ? (rowp(f, plane, 6, y, nx)[x] + df) : rowp(f, plane, 8, y + 1, nx)[x - 1];
+    T o[9];
+    collide<T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) rowp(buf, plane, q, y, nx)[x] = o[q];
+}
+
+// ------------------------------------------------------------------------------------------
+// LID-DRIVEN sweeps, vector form.  Lanes whose 16 bytes touch x=0 or x=nx-1, and the rows that
+// touch the bottom wall or the lid, run the single-node form; every other lane runs the same
+// shifted-vector code as the periodic sweeps (no wrap can occur there).
+template <typename T, int V, int BLOCK, bool PULL>
+__global__ void __launch_bounds__(BLOCK)
+k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
+{
+    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx) return;
+    const size_t plane = (size_t)g.ny * g.nx;
+    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+        const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
+        const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
+        const bool edge_lane = (x0 == 0) || (x0 + V == g.nx);
+        if (t || b || edge_lane) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const uint32_t x = x0 + i;
+                const bool l = (x == 0), r = (x == g.nx - 1);
+                if (PULL) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+                else      lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+            }
+            continue;
+        }
+        const uint32_t yu = y + 1, yd = y - 1;
+        T c[9][V];
+        if (PULL) {
+            load_u<T, V>(c[7], rowp(f, plane, 7, yu, g.nx) + (x0 + 1));
+            load_a<T, V>(c[4], rowp(f, plane, 4, yu, g.nx) + x0);
+            load_u<T, V>(c[8], rowp(f, plane, 8, yu, g.nx) + (x0 - 1));
+            load_u<T, V>(c[3], rowp(f, plane, 3, y, g.nx) + (x0 + 1));
+            load_a<T, V>(c[0], rowp(f, plane, 0, y, g.nx) + x0);
+            load_u<T, V>(c[1], rowp(f, plane, 1, y, g.nx) + (x0 - 1));
+            load_u<T, V>(c[6], rowp(f, plane, 6, yd, g.nx) + (x0 + 1));
+            load_a<T, V>(c[2], rowp(f, plane, 2, yd, g.nx) + x0);
+            load_u<T, V>(c[5], rowp(f, plane, 5, yd, g.nx) + (x0 - 1));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
+        }
+        T o[9][V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            T r[9];
+            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+                       c[8][i], om, r);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+        }
+        if (PULL) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
+        } else {
+            store_u<T, V>(rowp(buf, plane, 7, yd, g.nx) + (x0 - 1), o[7]);
+            store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
+            store_u<T, V>(rowp(buf, plane, 8, yd, g.nx) + (x0 + 1), o[8]);
+            store_u<T, V>(rowp(buf, plane, 3, y, g.nx) + (x0 - 1), o[3]);
+            store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
+            store_u<T, V>(rowp(buf, plane, 1, y, g.nx) + (x0 + 1), o[1]);
+            store_u<T, V>(rowp(buf, plane, 6, yu, g.nx) + (x0 - 1), o[6]);
+            store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
+            store_u<T, V>(rowp(buf, plane, 5, yu, g.nx) + (x0 + 1), o[5]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Scalar kernels: one node per lane over the rectangle [x_lo,x_hi) x [y_lo,y_hi).  Any nx.
+enum ScalarMode { kPullPeriodic = 0, kPushPeriodic = 1, kPullLid = 2, kPushLid = 3 };
+
+template <typename T, int MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint32_t x_lo,
+               uint32_t x_hi, int wrap_x, const T om, const T df_lid)
+{
+    const uint32_t x = x_lo + blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= x_hi) return;
+    const size_t plane = (size_t)g.ny * g.nx;
+    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+        if (MODE == kPullPeriodic || MODE == kPushPeriodic) {
+            // wrap by comparison: pull-push.cpp:255-258 / :277-280
+            const uint32_t xr = wrap_x ? ((x + 1 == g.nx) ? 0u : x + 1) : x + 1;
+            const uint32_t xl = wrap_x ? ((x == 0) ? g.nx - 1 : x - 1) : x - 1;
+            const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+            if (MODE == kPullPeriodic) pull_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            else                       push_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+        } else {
+            const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
+            const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
+            const bool l = (x == 0), r = (x == g.nx - 1);
+            if (MODE == kPullLid) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+            else                  lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+        }
+    }
+}
+
+// Ring of a halo'd array: pull_periodic_outer / push_periodic_outer (pull-push.cpp:335-429).
+// Lane i < nx-2 handles x=i+1 at y=1 and y=ny-2; lane nx-2+j, j < ny-4, handles y=j+2 at x=1 and
+// x=nx-2.
+template <typename T, bool PULL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t ny, const T om)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const size_t plane = (size_t)ny * nx;
+    const uint32_t n_tb = nx - 2, n_lr = (ny >= 4) ? ny - 4 : 0;
+    uint32_t xa, ya, xb, yb;
+    if (i < n_tb) {
+        xa = xb = i + 1; ya = 1; yb = ny - 2;
+    } else if (i < n_tb + n_lr) {
+        ya = yb = i - n_tb + 2; xa = 1; xb = nx - 2;
+    } else {
+        return;
+    }
+    if (PULL) {
+        pull_node<T>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        if (xb != xa || yb != ya)
+            pull_node<T>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+    } else {
+        push_node<T>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        if (xb != xa || yb != ya)
+            push_node<T>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Initialisation: broadcast a per-row table along x.  table is [9][rows]; array rows
+// [y_first, y_first+rows) are written.  Replaces the "initialize" / "initialize at rest"
+// dispatches (init.cpp:14-33, :37-48); the table holds what f_eq (init.cpp:57-84) returns.
+template <typename T, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_fill_rows(T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_first, uint32_t rows,
+            const T *__restrict__ table)
+{
+    const uint32_t x = blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= nx) return;
+    const size_t plane = (size_t)ny * nx;
+    for (uint32_t r = blockIdx.y; r < rows; r += gridDim.y) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) rowp(f, plane, q, y_first + r, nx)[x] = table[q * rows + r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Output path.  WHAT: 0 = ux,uy planes (compute_velocities, io.cpp:136-174), 1 = |u| plane
+// (io.cpp:236-238).
+template <typename T, int WHAT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_velocity(const T *__restrict__ f, T *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t y_lo,
+           uint32_t y_hi)
+{
+    const uint32_t x = blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= nx) return;
+    const size_t plane = (size_t)ny * nx;
+    const uint32_t rows = y_hi - y_lo;
+    for (uint32_t y = y_lo + blockIdx.y; y < y_hi; y += gridDim.y) {
+        T c[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
+        T ux, uy;
+        node_velocity<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], ux, uy);
+        const size_t o = (size_t)(y - y_lo) * nx + x;
+        if (WHAT == 0) {
+            out[o] = ux;
+            out[(size_t)rows * nx + o] = uy;
+        } else {
+            out[o] = node_speed<T>(ux, uy);
+        }
+    }
+}
+
+// Max |u| reduction (io.cpp:184-208).  Speeds are >= 0 or NaN, so the IEEE bit pattern of a valid
+// speed orders like an unsigned integer; key = bits+1, key 0 = "no node qualified".  Lanes reduce
+// with wavefront shuffles, waves through LDS, then one atomicMax per workgroup on *key.
+__device__ __forceinline__ uint32_t speed_key(float u)
+{
+    // NaN never wins (io.cpp:205: `if (u > local_max)`); -0.0f cannot occur from sqrtf(x*x+y*y).
+    return (u == u) ? (__float_as_uint(u) + 1u) : 0u;
+}
+
+template <typename T, int V, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_max_speed(const T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_lo, uint32_t y_hi,
+            uint32_t *__restrict__ key)
+{
+    const size_t plane = (size_t)ny * nx;
+    uint32_t best = 0;
+    const uint32_t nvec = nx / V;  // vector chunks per row (nx % V == 0 when V > 1)
+    for (uint32_t y = y_lo + blockIdx.y; y < y_hi; y += gridDim.y) {
+        for (uint32_t v = blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += gridDim.x * BLOCK) {
+            T c[9][V];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, nx) + (size_t)v * V);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                T ux, uy;
+                node_velocity<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i],
+                                 c[7][i], c[8][i], ux, uy);
+                // the reference narrows to float for sqrtf and keeps the float value (global.h:30)
+                const uint32_t k = speed_key(sqrtf((float)(ux * ux + uy * uy)));
+                best = (k > best) ? k : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const uint32_t other = __shfl_down(best, off, kWave);
+        best = (other > best) ? other : best;
+    }
+    __shared__ uint32_t wave_best[BLOCK / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) wave_best[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = wave_best[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / kWave; ++w) m = (wave_best[w] > m) ? wave_best[w] : m;
+        if (m != 0) atomicMax(key, m);
+    }
+}
+
+// Decode the key into one FLT (start value -1e30 as io.cpp:184 when no node qualified).
+template <typename T>
+__global__ void k_max_speed_finish(const uint32_t *__restrict__ key, T *__restrict__ out)
+{
+    const uint32_t k = *key;
+    *out = (k == 0) ? (T)-1e30 : (T)__uint_as_float(k - 1u);
+}
+
+}  // namespace lbm

@@ -1,0 +1,192 @@
+"""The reference's operator functions on device tensors.
+
+Each function keeps the name and argument meaning of the reference free function it replaces
+(src/init.h:13-18, src/pull-push.h:73-140, src/io.h:25 / io.cpp:136-208) and forwards to the C ABI
+(include/lbm_hip.h).  Populations are torch tensors of shape [9, NY, NX] (reference Dst_t with
+COALESCING=true, global.h:112, main.cpp:37-38), float32 or float64, contiguous, on a HIP device.
+Scalars that the reference passes as rank-0 device Views (DUI/DFL, global.h:121-147) are plain
+Python numbers here.  All calls are asynchronous on the tensor's current torch stream unless noted.
+
+There is no CPU path: a tensor that is not on a GPU is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import capi
+
+Q = 9
+
+
+def _prec(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return capi.F32
+    if t.dtype == torch.float64:
+        return capi.F64
+    raise TypeError(f"populations must be float32 or float64, got {t.dtype}")
+
+
+def _check_f(f: torch.Tensor, name: str = "f"):
+    if not isinstance(f, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not f.is_cuda:
+        raise RuntimeError(
+            f"{name} lives on {f.device}: the lattice kernels are HIP-only (gfx950); there is no CPU path")
+    if f.dim() != 3 or f.shape[0] != Q or not f.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous [9, NY, NX] tensor, got {tuple(f.shape)}")
+    return int(f.shape[2]), int(f.shape[1])
+
+
+def _check_pair(f, buf, nx=None, ny=None):
+    fx, fy = _check_f(f, "f")
+    bx, by = _check_f(buf, "buf")
+    if (fx, fy) != (bx, by) or f.dtype != buf.dtype or f.device != buf.device:
+        raise ValueError("f and buf must have the same shape, dtype and device")
+    if nx is not None and int(nx) != fx or ny is not None and int(ny) != fy:
+        raise ValueError(f"nx,ny = {nx},{ny} do not match the tensor shape {fx},{fy}")
+    return fx, fy
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _run(name: str, t: torch.Tensor, *args):
+    with torch.cuda.device(t.device):
+        capi.call(name, *args)
+
+
+# ---------------------------------------------------------------- initialisation (init.h) ----
+def init_shearwave(f, rho_init, u, y_below=0, y_glob=None, halo=0):
+    """init_shearwave (init.h:13, init.cpp:5-34).  halo = the reference's USE_MPI row offset."""
+    nx, ny = _check_f(f)
+    y_glob = ny if y_glob is None else y_glob
+    _run("lbm_init_shearwave", f, f.data_ptr(), _prec(f), nx, ny, float(rho_init), float(u),
+         int(y_below), int(y_glob), int(halo), _stream(f))
+
+
+def init_rest(f, rho_init):
+    """init_rest (init.h:18, init.cpp:36-49)."""
+    nx, ny = _check_f(f)
+    _run("lbm_init_rest", f, f.data_ptr(), _prec(f), nx, ny, float(rho_init), _stream(f))
+
+
+# ---------------------------------------------------------------- sweeps (pull-push.h) -------
+def pull_periodic_no_mpi(f, buf, nx, ny, om):
+    """pull_periodic_no_mpi (pull-push.h:84)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_pull_periodic_no_mpi", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om), _stream(f))
+
+
+def push_periodic_no_mpi(f, buf, nx, ny, om):
+    """push_periodic_no_mpi (pull-push.h:73)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_push_periodic_no_mpi", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om), _stream(f))
+
+
+def pull_periodic_rows(f, buf, om, y_lo, y_hi, wrap_y):
+    """Rows [y_lo,y_hi), x periodic; the slab form of pull_periodic_inner's y range (pull-push.h:95)."""
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_pull_periodic_rows", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(y_lo), int(y_hi), int(bool(wrap_y)), _stream(f))
+
+
+def push_periodic_rows(f, buf, om, y_lo, y_hi, wrap_y):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_push_periodic_rows", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(y_lo), int(y_hi), int(bool(wrap_y)), _stream(f))
+
+
+def pull_periodic_inner(f, buf, om, LX, LY, HX, HY):
+    """pull_periodic_inner (pull-push.h:95)."""
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_pull_periodic_inner", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(LX), int(LY), int(HX), int(HY), _stream(f))
+
+
+def push_periodic_inner(f, buf, om, LX, LY, HX, HY):
+    """push_periodic_inner (pull-push.h:107)."""
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_push_periodic_inner", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(LX), int(LY), int(HX), int(HY), _stream(f))
+
+
+def pull_periodic_outer(f, buf, om, nx, ny):
+    """pull_periodic_outer (pull-push.h:117)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_pull_periodic_outer", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om), _stream(f))
+
+
+def push_periodic_outer(f, buf, om, nx, ny):
+    """push_periodic_outer (pull-push.h:126)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_push_periodic_outer", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om), _stream(f))
+
+
+def push_lid_driven(f, buf, nx, ny, om, rho_eq, u_lid):
+    """push_lid_driven (pull-push.h:140)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_push_lid_driven", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), _stream(f))
+
+
+def pull_lid_driven(f, buf, nx, ny, om, rho_eq, u_lid):
+    """Pull form of the lid-driven cavity; the reference has no counterpart (main.cpp:72-74)."""
+    nx, ny = _check_pair(f, buf, nx, ny)
+    _run("lbm_pull_lid_driven", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), _stream(f))
+
+
+def push_lid_rows(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_push_lid_rows", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), int(y_lo), int(y_hi), int(y_goff), int(ny_glob), _stream(f))
+
+
+def pull_lid_rows(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_pull_lid_rows", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), int(y_lo), int(y_hi), int(y_goff), int(ny_glob), _stream(f))
+
+
+# ---------------------------------------------------------------- output path (io.cpp) -------
+def compute_velocities(vel, f, LX, LY, HX, HY):
+    """compute_velocities (io.cpp:136-174).  vel: [2, HY-LY, NX] (ux plane, uy plane); the x range
+    is always the full row (LX must be 0 and HX the row length)."""
+    nx, ny = _check_f(f)
+    if int(LX) != 0 or int(HX) != nx:
+        raise ValueError("compute_velocities works on full rows: LX must be 0 and HX == NX")
+    rows = int(HY) - int(LY)
+    if tuple(vel.shape) != (2, rows, nx) or vel.dtype != f.dtype or not vel.is_contiguous() or vel.device != f.device:
+        raise ValueError(f"vel must be a contiguous [2, {rows}, {nx}] tensor like f")
+    _run("lbm_compute_velocities", f, f.data_ptr(), vel.data_ptr(), _prec(f), nx, ny, int(LY), int(HY), _stream(f))
+
+
+def velocity_magnitudes(mag, f, LY, HY):
+    """|u| per node as the -ov output forms it (io.cpp:236-238).  mag: [HY-LY, NX]."""
+    nx, ny = _check_f(f)
+    rows = int(HY) - int(LY)
+    if tuple(mag.shape) != (rows, nx) or mag.dtype != f.dtype or not mag.is_contiguous() or mag.device != f.device:
+        raise ValueError(f"mag must be a contiguous [{rows}, {nx}] tensor like f")
+    _run("lbm_velocity_magnitudes", f, f.data_ptr(), mag.data_ptr(), _prec(f), nx, ny, int(LY), int(HY), _stream(f))
+
+
+def max_velocity_dev(out, f, LY=0, HY=None):
+    """MAX_VEL reduction of output() (io.cpp:184-208) into out[0] (1-element tensor like f, on the
+    device); asynchronous."""
+    nx, ny = _check_f(f)
+    HY = ny if HY is None else int(HY)
+    if out.numel() < 1 or out.dtype != f.dtype or out.device != f.device:
+        raise ValueError("out must be a device tensor of f's dtype with at least one element")
+    _run("lbm_max_velocity_dev", f, f.data_ptr(), out.data_ptr(), _prec(f), nx, ny, int(LY), HY, _stream(f))
+
+
+def max_velocity(f, LY=0, HY=None) -> float:
+    """MAX_VEL reduction delivered to the host (synchronises the stream)."""
+    nx, ny = _check_f(f)
+    HY = ny if HY is None else int(HY)
+    out = C.c_double(0.0)
+    _run("lbm_max_velocity", f, f.data_ptr(), _prec(f), nx, ny, int(LY), HY, _stream(f), C.byref(out))
+    return out.value

@@ -1,0 +1,136 @@
+"""Single-device time loop and text outputs of the reference driver, on the HIP operators.
+
+Mirrors run_simulation_single_node (reference src/main.cpp:31-89): allocate f/buf, initialise by
+scene, then per step {optional output BEFORE the step, one fused sweep, handle swap}; and output()
+(src/io.cpp:177-294) for the -omv / -ov / -ovf formats.
+"""
+from __future__ import annotations
+
+import io as _io
+from typing import Optional, TextIO
+
+import torch
+
+from . import ops
+
+SHEAR_WAVE, LID_DRIVEN = "shear", "lid"
+NONE, MAX_VEL, VEL_MAGS, VEL_FIELD = "none", "omv", "ov", "ovf"
+
+
+def fmt(v: float) -> str:
+    """C++ ostream default formatting of a float/double (precision 6, i.e. %g)."""
+    return "%g" % v
+
+
+class NaNEncountered(RuntimeError):
+    """-ov output met a NaN (reference io.cpp:239-243: message on stderr, exit code 1)."""
+
+    def __init__(self, x: int, y: int):
+        super().__init__(f"NaN encountered at x={x} y={y}")
+        self.x, self.y = x, y
+
+
+class Simulation:
+    """Two-grid, one-step D2Q9 BGK solver on one GPU.
+
+    scene:  "shear" (periodic shear-wave decay, default) or "lid" (lid-driven cavity)
+    scheme: "pull" or "push".  The reference's lid scene always pushes (main.cpp:72-74); here
+            scheme="pull" with scene="lid" selects the pull form of the same boundary conditions.
+    """
+
+    def __init__(self, nx: int, ny: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
+                 dtype: torch.dtype = torch.float32, omega: float = 0.5, rho: float = 1.0,
+                 u: float = 0.1, device="cuda:0"):
+        if scene not in (SHEAR_WAVE, LID_DRIVEN):
+            raise ValueError(f"unknown scene {scene!r}")
+        if scheme not in ("pull", "push"):
+            raise ValueError(f"unknown scheme {scheme!r}")
+        self.nx, self.ny = int(nx), int(ny)
+        self.scene, self.scheme = scene, scheme
+        self.omega, self.rho, self.u = float(omega), float(rho), float(u)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Simulation needs a HIP device; there is no CPU path")
+        self.f = torch.empty((9, self.ny, self.nx), dtype=dtype, device=self.device)
+        self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
+        self.t = 0
+        self._vel: Optional[torch.Tensor] = None
+        self._mag: Optional[torch.Tensor] = None
+        if scene == LID_DRIVEN:
+            ops.init_rest(self.f, self.rho)
+        else:
+            ops.init_shearwave(self.f, self.rho, self.u, 0, self.ny)
+
+    # -- one fused collide+stream step and the handle swap (main.cpp:71-84)
+    def step(self, n: int = 1) -> None:
+        for _ in range(n):
+            if self.scene == LID_DRIVEN:
+                if self.scheme == "push":
+                    ops.push_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
+                else:
+                    ops.pull_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
+            elif self.scheme == "push":
+                ops.push_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
+            else:
+                ops.pull_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
+            self.f, self.buf = self.buf, self.f
+            self.t += 1
+
+    def max_velocity(self) -> float:
+        return ops.max_velocity(self.f)
+
+    def velocities(self) -> torch.Tensor:
+        """[2, NY, NX] device tensor: ux plane, uy plane."""
+        if self._vel is None:
+            self._vel = torch.empty((2, self.ny, self.nx), dtype=self.f.dtype, device=self.device)
+        ops.compute_velocities(self._vel, self.f, 0, 0, self.nx, self.ny)
+        return self._vel
+
+    def velocity_magnitudes(self) -> torch.Tensor:
+        if self._mag is None:
+            self._mag = torch.empty((self.ny, self.nx), dtype=self.f.dtype, device=self.device)
+        ops.velocity_magnitudes(self._mag, self.f, 0, self.ny)
+        return self._mag
+
+    # -- output() of io.cpp:177-294
+    def output(self, kind: str, stream: TextIO) -> None:
+        if kind == MAX_VEL:
+            stream.write(fmt(self.max_velocity()) + ",")
+            stream.flush()
+        elif kind == VEL_MAGS:
+            mag = self.velocity_magnitudes().cpu().numpy()
+            _write_block(stream, mag, check_nan=True)
+        elif kind == VEL_FIELD:
+            vel = self.velocities().cpu().numpy()
+            _write_block(stream, vel[0], check_nan=False)
+            _write_block(stream, vel[1], check_nan=False)
+        elif kind != NONE:
+            raise ValueError(f"unknown output kind {kind!r}")
+
+    def run(self, steps: int, out_every: int = 0, kind: str = NONE, stream: Optional[TextIO] = None) -> str:
+        """The reference's main loop: output before the step when t % out_every == 0."""
+        own = stream is None
+        stream = _io.StringIO() if own else stream
+        for t in range(steps):
+            if out_every > 0 and t % out_every == 0:
+                self.output(kind, stream)
+            self.step()
+        return stream.getvalue() if own else ""
+
+
+def _write_block(stream: TextIO, a, check_nan: bool) -> None:
+    """NY lines (y=0 first) of NX comma-separated values, then a '#' line (io.cpp:234-254)."""
+    import numpy as np
+
+    if check_nan and np.isnan(a).any():
+        # the reference prints rows until it meets the NaN; report the first one in its scan order
+        ys, xs = np.nonzero(np.isnan(a))
+        for y in range(int(ys[0])):
+            stream.write(",".join(fmt(v) for v in a[y]) + "\n")
+        x = int(xs[0])
+        if x > 0:
+            stream.write(",".join(fmt(v) for v in a[int(ys[0]), :x]) + ",")
+        raise NaNEncountered(x, int(ys[0]))
+    for row in a:
+        stream.write(",".join(fmt(v) for v in row) + "\n")
+    stream.write("#\n")

@@ -1,0 +1,277 @@
+"""y-slab decomposition of the lattice over ranks (one process per GPU, torch.distributed).
+
+Replaces the reference's 2-D Cartesian MPI halo exchange (src/main.cpp:92-401) for one node of
+GPUs: the lattice is cut into contiguous y-slabs, every slab spans the full NX so the x wrap stays
+inside the sweep kernel, and each rank keeps one ghost row below and above its rows in every
+population plane -- local array [9][n+2][NX], interior rows 1..n.  In SoA storage a (channel, row)
+pair is already contiguous, so the three populations that cross a slab edge are sent straight from
+/ received straight into the population array: no pack or unpack kernels (the reference needs six,
+main.cpp:238-273, :339-374).
+
+Per step (pull):  edge rows 1 and n of buf are computed first on the compute stream; a second
+stream then sends them to the neighbours' ghost rows (RCCL send/recv over xGMI when the backend
+is "nccl") while the compute stream updates the interior rows 2..n-1; the next step's edge rows
+wait for the exchange.  Push works the same way with the roles of ghost and edge rows swapped
+(values pushed into a ghost row belong to the neighbour's edge row).
+
+The multi-rank result is bit-identical to the single-device result: slabs are initialised from the
+global row index (the reference's own offset is wrong for ranks > 0, main.cpp:141-144, and is not
+reproduced).
+
+Kernels are reached through a small backend object so that the exchange schedule can be exercised
+on CPU ranks in tests; the default backend is the HIP operator layer and refuses CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+SHEAR_WAVE, LID_DRIVEN = "shear", "lid"
+
+# populations that leave a slab through its top edge (cy=+1) / bottom edge (cy=-1)
+UP_CHANNELS = (2, 5, 6)
+DOWN_CHANNELS = (4, 7, 8)
+
+
+def slab_rows(ny_glob: int, world: int, rank: int) -> Tuple[int, int]:
+    """(rows owned, global index of the first owned row): remainder rows go to the lowest ranks
+    (as reference main.cpp:133-141 does)."""
+    base, rem = divmod(ny_glob, world)
+    n = base + (1 if rank < rem else 0)
+    y_below = rank * base + min(rank, rem)
+    return n, y_below
+
+
+class HipBackend:
+    """Slab kernels on the HIP operator layer (lbm_amd.ops)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def init_shearwave(self, f, rho, u, y_below, y_glob):
+        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=1)
+
+    def init_rest(self, f, rho):
+        self.ops.init_rest(f, rho)
+
+    def pull_periodic_rows(self, f, buf, om, y_lo, y_hi):
+        self.ops.pull_periodic_rows(f, buf, om, y_lo, y_hi, False)
+
+    def push_periodic_rows(self, f, buf, om, y_lo, y_hi):
+        self.ops.push_periodic_rows(f, buf, om, y_lo, y_hi, False)
+
+    def pull_lid_rows(self, f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob):
+        self.ops.pull_lid_rows(f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob)
+
+    def push_lid_rows(self, f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob):
+        self.ops.push_lid_rows(f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob)
+
+    def max_velocity_dev(self, out, f, y_lo, y_hi):
+        self.ops.max_velocity_dev(out, f, y_lo, y_hi)
+
+    def compute_velocities(self, vel, f, y_lo, y_hi):
+        self.ops.compute_velocities(vel, f, 0, y_lo, f.shape[2], y_hi)
+
+
+class SlabSimulation:
+    """One rank's slab of a global NX x NY lattice.
+
+    Requires an initialised torch.distributed process group unless world size is 1 (then the
+    periodic neighbours are the rank itself and rows are copied locally).
+    """
+
+    def __init__(self, nx: int, ny_glob: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
+                 dtype: torch.dtype = torch.float32, omega: float = 0.5, rho: float = 1.0,
+                 u: float = 0.1, device="cuda:0", backend=None, group=None, overlap: bool = True):
+        if scene not in (SHEAR_WAVE, LID_DRIVEN):
+            raise ValueError(f"unknown scene {scene!r}")
+        if scheme not in ("pull", "push"):
+            raise ValueError(f"unknown scheme {scheme!r}")
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.nx, self.ny_glob = int(nx), int(ny_glob)
+        self.scene, self.scheme = scene, scheme
+        self.omega, self.rho, self.u = float(omega), float(rho), float(u)
+        self.device = torch.device(device)
+        self.n, self.y_below = slab_rows(self.ny_glob, self.world, self.rank)
+        if self.n < 1:
+            raise ValueError(f"rank {self.rank} owns no rows: NY={ny_glob} < world size {self.world}")
+        if backend is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("SlabSimulation needs a HIP device; there is no CPU path")
+            backend = HipBackend()
+        self.backend = backend
+        self.periodic = scene == SHEAR_WAVE
+        # neighbours along y; None = wall (lid scene at the first / last rank)
+        self.lower: Optional[int] = (self.rank - 1) % self.world if (self.periodic or self.rank > 0) else None
+        self.upper: Optional[int] = (self.rank + 1) % self.world if (self.periodic or self.rank < self.world - 1) else None
+
+        n = self.n
+        self.f = torch.empty((9, n + 2, self.nx), dtype=dtype, device=self.device)
+        self.buf = torch.empty_like(self.f)
+        # ghost rows start defined (a wall-side ghost row is never read by the lid kernels, a
+        # periodic one is overwritten by the first exchange)
+        self.f[:, 0].zero_(); self.f[:, n + 1].zero_()
+        self.buf[:, 0].zero_(); self.buf[:, n + 1].zero_()
+        self._max = torch.empty(2, dtype=dtype, device=self.device)
+        self.t = 0
+
+        self.cuda = self.device.type == "cuda"
+        self.overlap = bool(overlap) and self.cuda
+        if self.cuda:
+            self.compute_stream = torch.cuda.current_stream(self.device)
+            self.comm_stream = torch.cuda.Stream(self.device) if self.overlap else self.compute_stream
+            self._edges_done = torch.cuda.Event()
+            self._halo_done = torch.cuda.Event()
+        self._halo_pending = False
+
+        if scene == LID_DRIVEN:
+            backend.init_rest(self.f, self.rho)
+        else:
+            backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob)
+        if self.scheme == "pull":
+            # pull reads ghost rows of f: fill them from the neighbours' initial edge rows
+            self._exchange(self.f, pull=True)
+            self._join_halo()
+
+    # ------------------------------------------------------------------ exchange -------------
+    def _exchange(self, a: torch.Tensor, pull: bool) -> None:
+        """Halo-row exchange on array `a` (runs on the communication stream).
+
+        pull: my edge rows -> the neighbours' ghost rows.   send a[DOWN,1] down, a[UP,n] up;
+              receive a[UP,0] from below, a[DOWN,n+1] from above.
+        push: my ghost rows -> the neighbours' edge rows.   send a[DOWN,0] down, a[UP,n+1] up;
+              receive a[UP,1] from below, a[DOWN,n] from above.
+        """
+        n = self.n
+        if pull:
+            s_dn, s_up, r_dn, r_up = 1, n, 0, n + 1
+        else:
+            s_dn, s_up, r_dn, r_up = 0, n + 1, 1, n
+        if self.cuda:
+            if self.overlap:
+                self._edges_done.record(self.compute_stream)
+                self.comm_stream.wait_event(self._edges_done)
+            ctx = torch.cuda.stream(self.comm_stream)
+        else:
+            ctx = _NullCtx()
+        with ctx:
+            if self.world == 1:
+                if self.lower is not None:  # periodic: the neighbour is this rank itself
+                    for q in DOWN_CHANNELS:
+                        a[q, r_up].copy_(a[q, s_dn])
+                    for q in UP_CHANNELS:
+                        a[q, r_dn].copy_(a[q, s_up])
+            else:
+                # Matching between one pair of ranks is by issue order (RCCL has no tags): what I
+                # send down is what the lower rank receives "from above", so sends go [down, up] and
+                # receives [from above, from below]; with two ranks both neighbours are the same
+                # peer and this order is what keeps the two directions apart.
+                p2p: List[dist.P2POp] = []
+                if self.lower is not None:
+                    for q in DOWN_CHANNELS:
+                        p2p.append(dist.P2POp(dist.isend, a[q, s_dn], self._peer(self.lower), self.group, tag=q))
+                if self.upper is not None:
+                    for q in UP_CHANNELS:
+                        p2p.append(dist.P2POp(dist.isend, a[q, s_up], self._peer(self.upper), self.group, tag=q))
+                if self.upper is not None:
+                    for q in DOWN_CHANNELS:
+                        p2p.append(dist.P2POp(dist.irecv, a[q, r_up], self._peer(self.upper), self.group, tag=q))
+                if self.lower is not None:
+                    for q in UP_CHANNELS:
+                        p2p.append(dist.P2POp(dist.irecv, a[q, r_dn], self._peer(self.lower), self.group, tag=q))
+                if p2p:
+                    for req in dist.batch_isend_irecv(p2p):
+                        req.wait()
+            if self.cuda and self.overlap:
+                self._halo_done.record(self.comm_stream)
+        self._halo_pending = True
+
+    def _peer(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def _join_halo(self) -> None:
+        """Make the compute stream wait for the last exchange."""
+        if self._halo_pending and self.cuda and self.overlap:
+            self.compute_stream.wait_event(self._halo_done)
+        self._halo_pending = False
+
+    # ------------------------------------------------------------------ sweeps ---------------
+    def _sweep(self, y_lo: int, y_hi: int) -> None:
+        if y_lo >= y_hi:
+            return
+        b, f, buf = self.backend, self.f, self.buf
+        if self.scene == LID_DRIVEN:
+            args = (f, buf, self.omega, self.rho, self.u, y_lo, y_hi, self.y_below - 1, self.ny_glob)
+            (b.pull_lid_rows if self.scheme == "pull" else b.push_lid_rows)(*args)
+        elif self.scheme == "pull":
+            b.pull_periodic_rows(f, buf, self.omega, y_lo, y_hi)
+        else:
+            b.push_periodic_rows(f, buf, self.omega, y_lo, y_hi)
+
+    def step(self, nsteps: int = 1) -> None:
+        n = self.n
+        pull = self.scheme == "pull"
+        for _ in range(nsteps):
+            # edge rows first (they are what the neighbours wait for) ...
+            self._join_halo()
+            self._sweep(1, 2)
+            if n >= 2:
+                self._sweep(n, n + 1)
+            # ... exchange them on the second stream while the interior rows are updated
+            self._exchange(self.buf, pull=pull)
+            self._sweep(2, n)
+            if not pull:
+                # pushed values received from the neighbours land in rows the next step reads
+                self._join_halo()
+            self.f, self.buf = self.buf, self.f
+            self.t += 1
+
+    # ------------------------------------------------------------------ observables ----------
+    def max_velocity(self) -> float:
+        """Global max |u| (reference io.cpp:184-216: local reduce, then MPI_Reduce(MAX))."""
+        self._join_halo()
+        self.backend.max_velocity_dev(self._max, self.f, 1, self.n + 1)
+        if self.world > 1:
+            dist.all_reduce(self._max[:1], op=dist.ReduceOp.MAX, group=self.group)
+        return float(self._max[0].item())
+
+    def interior(self) -> torch.Tensor:
+        """This rank's rows without the ghost rows: [9, n, NX] (a view)."""
+        self._join_halo()
+        return self.f[:, 1:self.n + 1]
+
+    def gather_populations(self) -> Optional[torch.Tensor]:
+        """Rank 0 gets the global [9, NY, NX] populations (for tests / small outputs)."""
+        mine = self.interior().contiguous()
+        if self.world == 1:
+            return mine
+        if self.rank == 0:
+            parts = [mine]
+            for r in range(1, self.world):
+                nr, _ = slab_rows(self.ny_glob, self.world, r)
+                part = torch.empty((9, nr, self.nx), dtype=mine.dtype, device=self.device)
+                dist.recv(part, self._peer(r), group=self.group)
+                parts.append(part)
+            return torch.cat(parts, dim=1)
+        dist.send(mine, self._peer(0), group=self.group)
+        return None
+
+    def synchronize(self) -> None:
+        if self.cuda:
+            self._join_halo()
+            torch.cuda.synchronize(self.device)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

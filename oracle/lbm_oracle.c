@@ -1,0 +1,52 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  CPU oracle for the D2Q9 BGK collide-and-stream path.
+ *
+ * Instantiates lbm_oracle_impl.h for float (suffix _f32) and double (suffix _f64).  Only tests,
+ * the smoke check and the benchmark's CPU-baseline leg may load the resulting library; the
+ * product path never does.
+ *
+ * Parity pin: the reference cannot be built here (it needs Kokkos 4.5.01 fetched from the network
+ * and MPI headers, reference CMakeLists.txt:43-50,69), so this restatement is pinned by the
+ * reference's own recorded results: the five -omv shear-wave decay series in docs/decays.js and
+ * the analytic viscosity nu = (1/omega - 1/2)/3 that shear-wave.py:55 compares against.  No
+ * population-level fixture exists in the reference; population-level parity of the last bit of
+ * sinf (init.cpp:26) is therefore unpinned.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define FLT float
+#define SUFFIX _f32
+#include "lbm_oracle_impl.h"
+#undef FLT
+#undef SUFFIX
+
+#define FLT double
+#define SUFFIX _f64
+#include "lbm_oracle_impl.h"
+#undef FLT
+#undef SUFFIX
+
+/* Library self-description, so a loader can check what it got. */
+const char *orc_build_info(void)
+{
+    return "lbm oracle: C restatement, -ffp-contract=off, OpenMP over rows";
+}
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* Threads the row loops run on (for reporting a CPU baseline). */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,156 @@
+"""The CPU oracle against the reference's own recorded results and against itself.
+
+Pins (all from files the reference ships): docs/decays.js -> tests/golden/decays.json (five -omv
+series, 1000x1000 fp32), the viscosity table of docs/index.qmd:288-296, and the analytic decay
+law nu=(1/omega-1/2)/3 used by shear-wave.py:55,78.  The reference cannot be built here, and it
+holds no population-level fixture, so bit-level behaviour of the oracle is pinned only through
+these velocity-level series.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+@pytest.fixture(scope="module")
+def decays(golden_dir):
+    with open(os.path.join(golden_dir, "decays.json")) as fh:
+        return json.load(fh)
+
+
+# Recorded values carry 6 significant digits.  The recording build let the compiler contract
+# a*b+c into FMAs (reference CMakeLists.txt:18-19); in fp32 that alone moves this observable by up to
+# 2.4e-5 relative after 1000 steps (measured: omega=0.8 gives 0.0990198 without contraction,
+# 0.0990174 with it -- the recorded value).  So the strict oracle is held to 5e-5 and the
+# contraction build of the same source to 1e-5.
+DECAY_RTOL_STRICT = 5e-5
+DECAY_RTOL_FMA = 1e-5
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_oracle_matches_recorded_decay_series(decays, idx):
+    s = decays["series"][idx]
+    nsamp = 3  # t = 0, 500, 1000 (the full 400-sample series is checked on the GPU)
+    steps = (nsamp - 1) * decays["every"] + 1
+    _, samples = orc.run("shear", "pull", decays["nx"], decays["ny"], steps, s["omega"], np.float32,
+                         rho=decays["rho0"], u=decays["u0"], out_every=decays["every"])
+    assert len(samples) == nsamp
+    got = np.array([float(orc.fmt(v)) for v in samples])
+    want = np.array(s["max_us"][:nsamp])
+    np.testing.assert_allclose(got, want, rtol=DECAY_RTOL_STRICT)
+
+
+@pytest.mark.parametrize("idx", [1, 3])
+def test_contracting_oracle_build_matches_recorded_decay_series(decays, idx):
+    s = decays["series"][idx]
+    with orc.variant("fma"):
+        _, samples = orc.run("shear", "pull", decays["nx"], decays["ny"], 1001, s["omega"], np.float32,
+                             rho=decays["rho0"], u=decays["u0"], out_every=decays["every"])
+    got = np.array([float(orc.fmt(v)) for v in samples])
+    np.testing.assert_allclose(got, np.array(s["max_us"][:3]), rtol=DECAY_RTOL_FMA)
+
+
+@pytest.mark.parametrize("dtype,budget", [(np.float32, 1e-5), (np.float64, 1e-12)])
+def test_fma_contraction_stays_inside_the_parity_budget(dtype, budget):
+    # the compiler freedom the reference's build leaves open must not eat the parity tolerance
+    for scene, scheme in (("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")):
+        a, _ = orc.run(scene, scheme, 128, 96, 2000, 0.5, dtype)
+        with orc.variant("fma"):
+            b, _ = orc.run(scene, scheme, 128, 96, 2000, 0.5, dtype)
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() < 0.5 * budget
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+def test_oracle_decay_follows_analytic_viscosity(dtype, scheme):
+    # u(t) = u0 exp(-nu (2 pi / NY)^2 t), nu = (1/omega - 1/2)/3   (shear-wave.py:55,78)
+    nx, ny, omega, every = 16, 128, 0.8, 200
+    _, samples = orc.run("shear", scheme, nx, ny, 2001, omega, dtype, out_every=every)
+    t = np.arange(len(samples)) * every
+    nu_fit = -np.polyfit(t, np.log(np.array(samples, dtype=np.float64)), 1)[0] / (2 * math.pi / ny) ** 2
+    nu = (1 / omega - 0.5) / 3
+    assert abs(nu_fit - nu) / nu < 2e-3
+
+
+def test_viscosity_table_is_the_analytic_curve(decays):
+    for row in decays["viscosity_table"]:
+        nu = (1 / row["omega"] - 0.5) / 3
+        assert abs(nu - row["expected"]) < 5e-5
+        assert abs(row["measured"] - nu) / nu < 5e-3
+
+
+def test_known_text_outputs():
+    # -nx 64 -ny 64 -w 0.5 -s 2001 -of 500 -omv, fp64: pull and push print the same five values
+    for scheme in ("pull", "push"):
+        _, s = orc.run("shear", scheme, 64, 64, 2001, 0.5, np.float64, out_every=500)
+        assert ",".join(orc.fmt(v) for v in s) == "0.1,0.00918508,0.000838386,7.65257e-05,6.98548e-06"
+    # -nx 4 -ny 6 -s 1 -of 1 -ov, fp32: |u| rows at t=0 are u0*|sin(2 pi y/6)|
+    f = orc.alloc(4, 6, np.float32)
+    orc.init_shearwave(f, np.float32(1.0), np.float32(0.1))
+    mag = orc.velocity_magnitudes(f)
+    rows = [",".join(orc.fmt(v) for v in r) for r in mag]
+    assert rows[0] == "0,0,0,0" or rows[0].startswith("0,") or float(rows[0].split(",")[0]) < 1e-8
+    assert rows[1] == "0.0866025,0.0866025,0.0866025,0.0866025"
+    assert rows[2] == rows[1] and rows[4] == rows[1] and rows[5] == rows[1]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mass_is_conserved(dtype):
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    for scene, scheme in (("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")):
+        f, _ = orc.run(scene, scheme, 40, 28, 300, 1.3, dtype)
+        total = f.sum(dtype=np.float64)
+        assert abs(total - 40 * 28) / (40 * 28) < tol, (scene, scheme, total)
+
+
+def test_push_state_is_streamed_pull_state():
+    # push_N = S(C(push_{N-1})), pull_N = C(S(pull_{N-1})) and C(f0)=f0 up to rounding, so the
+    # macroscopic velocities of the two schemes agree to rounding after the same number of steps
+    fa, _ = orc.run("shear", "pull", 24, 36, 50, 0.7, np.float64)
+    fb, _ = orc.run("shear", "push", 24, 36, 50, 0.7, np.float64)
+    np.testing.assert_allclose(orc.compute_velocities(fa), orc.compute_velocities(fb), atol=1e-14)
+    fa, _ = orc.run("lid", "pull", 24, 36, 200, 1.2, np.float64)
+    fb, _ = orc.run("lid", "push", 24, 36, 200, 1.2, np.float64)
+    np.testing.assert_allclose(orc.compute_velocities(fa), orc.compute_velocities(fb), atol=1e-13)
+
+
+def test_lid_drives_flow_to_the_right_under_the_lid():
+    f, _ = orc.run("lid", "push", 32, 32, 2000, 1.0, np.float64)
+    vel = orc.compute_velocities(f)
+    assert vel[0, -1].mean() > 0.02          # top row dragged along +x
+    assert abs(vel[0, 0].mean()) < 5e-3      # bottom row nearly at rest
+    assert not np.isnan(f).any()
+
+
+def test_rows_and_halo_forms_agree_with_the_full_sweep():
+    rng = np.random.default_rng(7)
+    nx, ny = 12, 9
+    for dtype in (np.float32, np.float64):
+        f = (1.0 / 9 + 0.01 * rng.standard_normal((9, ny, nx))).astype(dtype)
+        om = dtype(1.1)
+        full = np.empty_like(f); orc.pull_periodic_no_mpi(f, full, om)
+        # the same sweep on an array padded with periodic ghost rows/columns
+        pad = np.ascontiguousarray(np.pad(f, ((0, 0), (1, 1), (1, 1)), mode="wrap"))
+        out = np.zeros_like(pad)
+        orc.pull_periodic_inner(pad, out, om, 2, 2, nx, ny)
+        orc.pull_periodic_outer(pad, out, om)
+        np.testing.assert_array_equal(out[:, 1:-1, 1:-1], full)
+        # y-slab with ghost rows only
+        pady = np.ascontiguousarray(np.pad(f, ((0, 0), (1, 1), (0, 0)), mode="wrap"))
+        outy = np.zeros_like(pady)
+        orc.pull_rows(pady, outy, om, 1, ny + 1, False)
+        np.testing.assert_array_equal(outy[:, 1:-1], full)
+
+
+def test_max_velocity_ignores_nan_and_starts_at_minus_1e30():
+    f = orc.alloc(8, 4, np.float32)
+    orc.init_shearwave(f, np.float32(1), np.float32(0.1))
+    m0 = orc.max_velocity(f)
+    f[1, 2, 3] = np.nan
+    assert orc.max_velocity(f) == m0
+    f[:] = np.nan
+    assert orc.max_velocity(f) == np.float32(-1e30)
