@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos on the compute stream")
+    ap.add_argument("--threads-x", type=int, default=0, help="workgroup width hint (0 = built-in)")
+    ap.add_argument("--waves-per-cu", type=int, default=0, help="resident-wave cap hint (0 = built-in)")
     return ap.parse_args()
 
 
@@ -107,7 +109,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    from lbm_amd import Simulation, SlabSimulation
+    from lbm_amd import Simulation, SlabSimulation, capi
+    if args.threads_x or args.waves_per_cu:
+        capi.call("lbm_set_launch_shape", args.threads_x, args.waves_per_cu)
 
     dtype = torch.float32 if args.precision == "fp32" else torch.float64
     bytes_per_node = 72 if args.precision == "fp32" else 144

@@ -50,9 +50,10 @@ const char *lbm_last_error(void);
 int lbm_abi_version(void);
 
 /* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
- * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (multiple of 64, <=1024) and
- * rows handled by one workgroup.  0 keeps the built-in choice. */
-int lbm_set_launch_shape(unsigned threads_x, unsigned rows_per_block);
+ * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (64, 128, 256 or 512) and the
+ * cap on resident waves per compute unit for the sweep kernels (1..32; the sweeps stream fastest
+ * with about 8-12).  0 keeps the built-in choice for that parameter.  Process-wide. */
+int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu);
 
 /* ---------------------------------------------------------------- initialisation ----------- */
 

@@ -42,7 +42,18 @@ int fail(int status, const char *fmt, ...)
 
 // launch-shape hint (lbm_set_launch_shape)
 unsigned g_threads_x = 0;
-unsigned g_rows_per_block = 0;
+unsigned g_waves_per_cu = 0;
+
+// Measured on MI355X (16384^2, straight-line sweeps, nt stores, 64-lane workgroups): the achieved
+// HBM rate is flat at 4-6 resident waves per CU (fp32 pull 6.06-6.13 TB/s), falls off a cliff at 7
+// (5.6 TB/s; 8 and more 5.4-5.6) and collapses at 3 (3.8 TB/s, latency exposed).  A wave keeps 9 KiB
+// of loads and 9 KiB of stores in flight, so 7 waves x 32 CUs exceed the 4 MiB L2 of an XCD.
+// Residency is capped by giving every workgroup an unused dynamic-LDS allocation of
+// 160 KiB / (workgroups per CU).
+constexpr unsigned kDefaultThreadsX = 64;
+constexpr unsigned kDefaultWavesPerCU = 5;
+constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr size_t kMaxDynamicLds = 64 * 1024;
 
 constexpr uint64_t kMaxExtent = 0x7fffffffull;  // extents are 32-bit inside the kernels
 
@@ -88,16 +99,38 @@ int check_rows(uint64_t ny, uint64_t y_lo, uint64_t y_hi, bool needs_ghosts)
 
 unsigned pick_block(uint64_t lanes_per_row)
 {
-    unsigned b = g_threads_x ? g_threads_x : 256u;
+    unsigned b = g_threads_x ? g_threads_x : kDefaultThreadsX;
     // do not launch workgroups much wider than a row
     while (b > 64 && (uint64_t)b / 2 >= lanes_per_row) b /= 2;
     return b;
 }
 
+// Grid of the sweep kernels: one workgroup per (x chunk, row); rows are split over grid y and z
+// (lbm::block_row).
+dim3 sweep_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
+{
+    const uint64_t gy = rows < lbm::kRowsPerGridZ ? rows : lbm::kRowsPerGridZ;
+    const uint64_t gz = (rows + lbm::kRowsPerGridZ - 1) / lbm::kRowsPerGridZ;
+    return dim3((unsigned)((lanes_per_row + block - 1) / block), (unsigned)gy, (unsigned)gz);
+}
+
+// Dynamic-LDS bytes per workgroup that leave room for `waves` resident waves per CU.
+size_t residency_ballast(unsigned block)
+{
+    const unsigned waves = g_waves_per_cu ? g_waves_per_cu : kDefaultWavesPerCU;
+    const unsigned waves_per_block = block / 64;
+    unsigned blocks_per_cu = waves / waves_per_block;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (waves >= 32) return 0;  // hardware limit anyway
+    size_t bytes = (kLdsPerCU / blocks_per_cu) & ~(size_t)511;
+    if (bytes > kMaxDynamicLds) bytes = kMaxDynamicLds;
+    return bytes;
+}
+
+// Grid of the row-strided helper kernels (initialisation, velocity output).
 dim3 make_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
 {
-    const unsigned rpb = g_rows_per_block ? g_rows_per_block : 1u;
-    uint64_t gy = (rows + rpb - 1) / rpb;
+    uint64_t gy = rows;
     if (gy > 65535) gy = 65535;
     if (gy == 0) gy = 1;
     return dim3((unsigned)((lanes_per_row + block - 1) / block), (unsigned)gy, 1);
@@ -150,13 +183,14 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
     if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
-        const dim3 grid = make_grid(lanes, block, rows);
+        const dim3 grid = sweep_grid(lanes, block, rows);
+        const size_t lds = residency_ballast(block);
         LBM_FOR_BLOCK(block,
-            if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), 0, stream, f, buf, g, om);
-            else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), 0, stream, f, buf, g, om))
+            if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
+            else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
     } else {
         const unsigned block = pick_block(nx);
-        const dim3 grid = make_grid(nx, block, rows);
+        const dim3 grid = sweep_grid(nx, block, rows);
         constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
@@ -185,7 +219,7 @@ int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     if (LX >= HX || LY >= HY) return LBM_OK;
     const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
     const unsigned block = pick_block(HX - LX);
-    const dim3 grid = make_grid(HX - LX, block, HY - LY);
+    const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
     constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
     LBM_FOR_BLOCK(block,
         hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, (const T *)f_,
@@ -250,12 +284,13 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
     if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
-        const dim3 grid = make_grid(lanes, block, rows);
+        const dim3 grid = sweep_grid(lanes, block, rows);
+        const size_t lds = residency_ballast(block);
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), 0, stream, f, buf, g, om, df))
+            hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {
         const unsigned block = pick_block(nx);
-        const dim3 grid = make_grid(nx, block, rows);
+        const dim3 grid = sweep_grid(nx, block, rows);
         constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
@@ -447,12 +482,14 @@ const char *lbm_last_error(void) { return g_err; }
 
 int lbm_abi_version(void) { return 1; }
 
-int lbm_set_launch_shape(unsigned threads_x, unsigned rows_per_block)
+int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu)
 {
     if (threads_x != 0 && threads_x != 64 && threads_x != 128 && threads_x != 256 && threads_x != 512)
         return fail(LBM_ERR_INVALID_ARGUMENT, "threads_x must be 0, 64, 128, 256 or 512 (got %u)", threads_x);
+    if (waves_per_cu > 32)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "waves_per_cu must be 0..32 (got %u)", waves_per_cu);
     g_threads_x = threads_x;
-    g_rows_per_block = rows_per_block;
+    g_waves_per_cu = waves_per_cu;
     return LBM_OK;
 }
 

@@ -9,6 +9,11 @@
 //     aligned 128-bit accesses, shifted by one element; only the first and last lane of a row take
 //     the element-wise wrap path;
 //   * row base addresses are wave-uniform (SGPR), the per-lane part is one 32-bit x offset;
+//   * one wave handles one 1 KiB chunk of one row, straight-line (no loop): measured on MI355X the
+//     chip streams fastest with a huge grid of short waves dispatched in address order, about
+//     8-12 resident waves per CU (more bytes in flight lower the achieved HBM rate), and
+//     non-temporal stores for the write stream (+7 %); the host caps residency with an otherwise
+//     unused dynamic-LDS allocation;
 //   * all scalars (nx, ny, omega, ...) are kernel arguments;
 //   * arithmetic follows the reference's expression trees with FMA contraction off, so results
 //     are bit-identical to a strict IEEE evaluation of the reference source.
@@ -47,13 +52,14 @@ __device__ __forceinline__ void load_u(T (&r)[V], const T *p)
 #pragma unroll
     for (int i = 0; i < V; ++i) r[i] = v[i];
 }
+// Stores are non-temporal: the write stream is never re-read within a sweep.
 template <typename T, int V>
 __device__ __forceinline__ void store_a(T *p, const T (&r)[V])
 {
     typename VecTypes<T, V>::vec_t v;
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = r[i];
-    *reinterpret_cast<typename VecTypes<T, V>::vec_a *>(p) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecTypes<T, V>::vec_a *>(p));
 }
 template <typename T, int V>
 __device__ __forceinline__ void store_u(T *p, const T (&r)[V])
@@ -61,7 +67,7 @@ __device__ __forceinline__ void store_u(T *p, const T (&r)[V])
     typename VecTypes<T, V>::vec_t v;
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = r[i];
-    *reinterpret_cast<typename VecTypes<T, V>::vec_u *>(p) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecTypes<T, V>::vec_u *>(p));
 }
 
 // r[i] = row[(x0 + i - 1) mod nx]   (values arriving from the left neighbour, periodic in x)
@@ -195,6 +201,13 @@ __device__ __forceinline__ T *rowp(T *base, size_t plane, int q, uint32_t y, uin
     return base + ((size_t)q * plane + (size_t)y * nx);
 }
 
+// Row handled by this workgroup: grid = (x chunks, rows mod kRowsPerGridZ, rows / kRowsPerGridZ).
+constexpr uint32_t kRowsPerGridZ = 32768;
+__device__ __forceinline__ uint32_t block_row(const Geom &g)
+{
+    return g.y_lo + blockIdx.z * kRowsPerGridZ + blockIdx.y;
+}
+
 __device__ __forceinline__ uint32_t row_up(const Geom &g, uint32_t y)
 {
     return g.wrap_y ? ((y + 1 == g.ny) ? 0u : y + 1) : y + 1;
@@ -206,74 +219,110 @@ __device__ __forceinline__ uint32_t row_down(const Geom &g, uint32_t y)
 
 // ------------------------------------------------------------------------------------------
 // PERIODIC PULL, vector form.  Replaces the "pull periodic" dispatch (pull-push.cpp:268-288) and
-// its device function pull_periodic (:5-73).  Grid: x = 16-byte chunks of a row, y = rows
-// (strided).  Requires nx % V == 0, nx >= 2V.
+// its device function pull_periodic (:5-73).  Grid: x = 16-byte chunks of a row, y/z = rows.
+// Requires nx % V == 0, nx >= 2V.
+//
+// All nine loads are issued back to back with no branch between them.  The shifted loads of the
+// first and last lane of a row reach one element outside the row; that element is still inside
+// the array (channels 1,5,8 are never plane 0, channels 3,6,7 never plane 8), its value is
+// replaced afterwards by the periodic neighbour, and only those two lanes take that branch.
 template <typename T, int V, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
     const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
     if (x0 >= g.nx) return;
+    const uint32_t y = block_row(g);
+    if (y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
-        const uint32_t yu = row_up(g, y), yd = row_down(g, y);
-        T c0[V], c1[V], c2[V], c3[V], c4[V], c5[V], c6[V], c7[V], c8[V];
-        // gather: pull-push.cpp:13-21
-        load_from_right<T, V>(c7, rowp(f, plane, 7, yu, g.nx), x0, g.nx);
-        load_a<T, V>(c4, rowp(f, plane, 4, yu, g.nx) + x0);
-        load_from_left<T, V>(c8, rowp(f, plane, 8, yu, g.nx), x0, g.nx);
-        load_from_right<T, V>(c3, rowp(f, plane, 3, y, g.nx), x0, g.nx);
-        load_a<T, V>(c0, rowp(f, plane, 0, y, g.nx) + x0);
-        load_from_left<T, V>(c1, rowp(f, plane, 1, y, g.nx), x0, g.nx);
-        load_from_right<T, V>(c6, rowp(f, plane, 6, yd, g.nx), x0, g.nx);
-        load_a<T, V>(c2, rowp(f, plane, 2, yd, g.nx) + x0);
-        load_from_left<T, V>(c5, rowp(f, plane, 5, yd, g.nx), x0, g.nx);
-        T o[9][V];
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            T r[9];
-            collide<T>(c0[i], c1[i], c2[i], c3[i], c4[i], c5[i], c6[i], c7[i], c8[i], om, r);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
+    const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+    const T *r7 = rowp(f, plane, 7, yu, g.nx), *r4 = rowp(f, plane, 4, yu, g.nx), *r8 = rowp(f, plane, 8, yu, g.nx);
+    const T *r3 = rowp(f, plane, 3, y, g.nx), *r0 = rowp(f, plane, 0, y, g.nx), *r1 = rowp(f, plane, 1, y, g.nx);
+    const T *r6 = rowp(f, plane, 6, yd, g.nx), *r2 = rowp(f, plane, 2, yd, g.nx), *r5 = rowp(f, plane, 5, yd, g.nx);
+    const ptrdiff_t xl = (ptrdiff_t)x0 - 1, xr = (ptrdiff_t)x0 + 1;
+    T c0[V], c1[V], c2[V], c3[V], c4[V], c5[V], c6[V], c7[V], c8[V];
+    // gather: pull-push.cpp:13-21
+    load_u<T, V>(c7, r7 + xr);
+    load_a<T, V>(c4, r4 + x0);
+    load_u<T, V>(c8, r8 + xl);
+    load_u<T, V>(c3, r3 + xr);
+    load_a<T, V>(c0, r0 + x0);
+    load_u<T, V>(c1, r1 + xl);
+    load_u<T, V>(c6, r6 + xr);
+    load_a<T, V>(c2, r2 + x0);
+    load_u<T, V>(c5, r5 + xl);
+    if (x0 == 0) {  // periodic wrap, pull-push.cpp:278
+        c8[0] = r8[g.nx - 1];
+        c1[0] = r1[g.nx - 1];
+        c5[0] = r5[g.nx - 1];
     }
+    if (x0 + V == g.nx) {  // pull-push.cpp:277
+        c7[V - 1] = r7[0];
+        c3[V - 1] = r3[0];
+        c6[V - 1] = r6[0];
+    }
+    T o[9][V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        T r[9];
+        collide<T>(c0[i], c1[i], c2[i], c3[i], c4[i], c5[i], c6[i], c7[i], c8[i], om, r);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
 }
 
 // PERIODIC PUSH, vector form.  Replaces "push periodic" (pull-push.cpp:246-266) and push_periodic
-// (:124-186): aligned reads of the node's own nine populations, shifted writes.
+// (:124-186): aligned reads of the node's own nine populations, shifted writes.  The first and
+// last lane of a row scatter element-wise (their shifted stores would leave the row); every other
+// lane issues nine vector stores with no branch between them.
 template <typename T, int V, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
     const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
     if (x0 >= g.nx) return;
+    const uint32_t y = block_row(g);
+    if (y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
-        const uint32_t yu = row_up(g, y), yd = row_down(g, y);
-        T c[9][V];
+    const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+    T c[9][V];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
-        T o[9][V];
+    for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
+    T o[9][V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            T r[9];
-            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
-                       c[8][i], om, r);
+    for (int i = 0; i < V; ++i) {
+        T r[9];
+        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+                   c[8][i], om, r);
 #pragma unroll
-            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
-        }
-        // scatter: pull-push.cpp:175-185
-        store_to_left<T, V>(rowp(buf, plane, 7, yd, g.nx), x0, g.nx, o[7]);
-        store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
-        store_to_right<T, V>(rowp(buf, plane, 8, yd, g.nx), x0, g.nx, o[8]);
-        store_to_left<T, V>(rowp(buf, plane, 3, y, g.nx), x0, g.nx, o[3]);
-        store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
-        store_to_right<T, V>(rowp(buf, plane, 1, y, g.nx), x0, g.nx, o[1]);
-        store_to_left<T, V>(rowp(buf, plane, 6, yu, g.nx), x0, g.nx, o[6]);
-        store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
-        store_to_right<T, V>(rowp(buf, plane, 5, yu, g.nx), x0, g.nx, o[5]);
+        for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+    }
+    // scatter: pull-push.cpp:175-185
+    T *w7 = rowp(buf, plane, 7, yd, g.nx), *w4 = rowp(buf, plane, 4, yd, g.nx), *w8 = rowp(buf, plane, 8, yd, g.nx);
+    T *w3 = rowp(buf, plane, 3, y, g.nx), *w0 = rowp(buf, plane, 0, y, g.nx), *w1 = rowp(buf, plane, 1, y, g.nx);
+    T *w6 = rowp(buf, plane, 6, yu, g.nx), *w2 = rowp(buf, plane, 2, yu, g.nx), *w5 = rowp(buf, plane, 5, yu, g.nx);
+    if (x0 != 0 && x0 + V != g.nx) {
+        store_u<T, V>(w7 + (x0 - 1), o[7]);
+        store_a<T, V>(w4 + x0, o[4]);
+        store_u<T, V>(w8 + (x0 + 1), o[8]);
+        store_u<T, V>(w3 + (x0 - 1), o[3]);
+        store_a<T, V>(w0 + x0, o[0]);
+        store_u<T, V>(w1 + (x0 + 1), o[1]);
+        store_u<T, V>(w6 + (x0 - 1), o[6]);
+        store_a<T, V>(w2 + x0, o[2]);
+        store_u<T, V>(w5 + (x0 + 1), o[5]);
+    } else {
+        store_to_left<T, V>(w7, x0, g.nx, o[7]);
+        store_a<T, V>(w4 + x0, o[4]);
+        store_to_right<T, V>(w8, x0, g.nx, o[8]);
+        store_to_left<T, V>(w3, x0, g.nx, o[3]);
+        store_a<T, V>(w0 + x0, o[0]);
+        store_to_right<T, V>(w1, x0, g.nx, o[1]);
+        store_to_left<T, V>(w6, x0, g.nx, o[6]);
+        store_a<T, V>(w2 + x0, o[2]);
+        store_to_right<T, V>(w5, x0, g.nx, o[5]);
     }
 }
 
@@ -383,7 +432,9 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
     const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
     if (x0 >= g.nx) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+    const uint32_t y = block_row(g);
+    if (y >= g.y_hi) return;
+    {
         const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
         const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
         const bool edge_lane = (x0 == 0) || (x0 + V == g.nx);
@@ -395,7 +446,7 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
                 if (PULL) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
                 else      lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
             }
-            continue;
+            return;
         }
         const uint32_t yu = y + 1, yd = y - 1;
         T c[9][V];
@@ -451,7 +502,9 @@ k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint3
     const uint32_t x = x_lo + blockIdx.x * BLOCK + threadIdx.x;
     if (x >= x_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    for (uint32_t y = g.y_lo + blockIdx.y; y < g.y_hi; y += gridDim.y) {
+    const uint32_t y = block_row(g);
+    if (y >= g.y_hi) return;
+    {
         if (MODE == kPullPeriodic || MODE == kPushPeriodic) {
             // wrap by comparison: pull-push.cpp:255-258 / :277-280
             const uint32_t xr = wrap_x ? ((x + 1 == g.nx) ? 0u : x + 1) : x + 1;

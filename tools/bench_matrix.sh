@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs bench.py over a small matrix and prints "label value frac" lines (GPU box only).
+set -u
+out=${1:-gpurun_out/bench_matrix.log}
+: > "$out"
+run() {
+  label="$1"; shift
+  line=$(timeout -k 10 300 python -u bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1)
+  python - "$label" "$line" >> "$out" <<'PY'
+import json, sys
+label, line = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads(line)
+    print(f"{label:44s} {d['value']:10.0f} MLUPS  {d['roofline']['achieved']:8.1f} GB/s  frac {d['roofline']['frac']:.3f}")
+except Exception as e:
+    print(f"{label:44s} FAILED {e} {line[:200]}")
+PY
+}
+for w in 6 8 10 12 16 32; do run "fp32 pull 16384^2 wpc=$w" --steps 30 --warmup 3 --waves-per-cu $w; done
+for t in 128 256; do run "fp32 pull 16384^2 tx=$t wpc=12" --steps 30 --warmup 3 --threads-x $t --waves-per-cu 12; done
+for w in 8 10 12 16 32; do run "fp32 push 16384^2 wpc=$w" --steps 30 --warmup 3 --scheme push --waves-per-cu $w; done
+for w in 8 10 12 16 32; do run "fp64 pull 16384^2 wpc=$w" --steps 20 --warmup 3 --precision fp64 --waves-per-cu $w; done
+for w in 8 12 32; do run "fp64 push 16384^2 wpc=$w" --steps 20 --warmup 3 --precision fp64 --scheme push --waves-per-cu $w; done
+for w in 8 12 32; do run "fp64 lid push 16384^2 wpc=$w" --steps 20 --warmup 3 --precision fp64 --scene lid --scheme push --waves-per-cu $w; done
+for w in 8 12 32; do run "fp64 lid pull 16384^2 wpc=$w" --steps 20 --warmup 3 --precision fp64 --scene lid --scheme pull --waves-per-cu $w; done
+for w in 8 12 16 32; do run "fp32 pull 1024^2 wpc=$w" --steps 2000 --warmup 100 --nx 1024 --ny-per-gpu 1024 --waves-per-cu $w; done
+cat "$out"
