@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -51,9 +52,21 @@ unsigned g_waves_per_cu = 0;
 // Residency is capped by giving every workgroup an unused dynamic-LDS allocation of
 // 160 KiB / (workgroups per CU).
 constexpr unsigned kDefaultThreadsX = 64;
-constexpr unsigned kDefaultWavesPerCU = 5;
+constexpr unsigned kDefaultWavesPerCU_f32 = 6;  // top of the plateau for fp32 (4096^2 .. 32768x8192)
+constexpr unsigned kDefaultWavesPerCU_f64 = 5;  // fp64: 4 is best by 1 % but sits on the cliff to 3
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr size_t kMaxDynamicLds = 64 * 1024;
+
+// Re-deal workgroups so that one XCD walks whole rows (lbm::block_coords).  Off by default:
+// measured on MI355X (16384^2) it removes the 8 % FETCH_SIZE excess of the plain mapping but lowers
+// the achieved rate (fp32 pull 6.1 -> 5.7 TB/s, fp64 pull 5.8 -> 5.6); the excess lines are cheap
+// (served on-die), the lost address-order locality is not.  LBM_XCD_ROWS=1 enables it.
+int xcd_rows_default()
+{
+    const char *e = getenv("LBM_XCD_ROWS");
+    return e ? atoi(e) : 0;
+}
+int g_xcd_rows = xcd_rows_default();
 
 constexpr uint64_t kMaxExtent = 0x7fffffffull;  // extents are 32-bit inside the kernels
 
@@ -115,9 +128,10 @@ dim3 sweep_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
 }
 
 // Dynamic-LDS bytes per workgroup that leave room for `waves` resident waves per CU.
-size_t residency_ballast(unsigned block)
+size_t residency_ballast(unsigned block, size_t elem_size)
 {
-    const unsigned waves = g_waves_per_cu ? g_waves_per_cu : kDefaultWavesPerCU;
+    const unsigned waves = g_waves_per_cu ? g_waves_per_cu
+                                          : (elem_size == 4 ? kDefaultWavesPerCU_f32 : kDefaultWavesPerCU_f64);
     const unsigned waves_per_block = block / 64;
     unsigned blocks_per_cu = waves / waves_per_block;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -140,6 +154,7 @@ lbm::Geom make_geom(uint64_t nx, uint64_t ny, uint64_t y_lo, uint64_t y_hi, int 
                     int64_t y_goff = 0, uint64_t ny_glob = 0)
 {
     lbm::Geom g;
+    g.xcd_rows = g_xcd_rows;
     g.nx = (uint32_t)nx;
     g.ny = (uint32_t)ny;
     g.y_lo = (uint32_t)y_lo;
@@ -184,7 +199,7 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block);
+        const size_t lds = residency_ballast(block, sizeof(T));
         LBM_FOR_BLOCK(block,
             if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
             else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
@@ -285,7 +300,7 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block);
+        const size_t lds = residency_ballast(block, sizeof(T));
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {

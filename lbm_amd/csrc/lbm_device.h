@@ -180,6 +180,7 @@ __device__ __forceinline__ T node_speed(const T ux, const T uy)
 // ------------------------------------------------------------------------------------------
 // Geometry shared by all sweeps.  Array is [9][ny][nx]; plane = ny*nx elements.
 struct Geom {
+    int xcd_rows;     // != 0: give each XCD whole rows (see block_coords)
     uint32_t nx;      // row length
     uint32_t ny;      // rows in the array (incl. ghost rows if any)
     uint32_t y_lo;    // first row to update
@@ -208,6 +209,27 @@ __device__ __forceinline__ uint32_t block_row(const Geom &g)
     return g.y_lo + blockIdx.z * kRowsPerGridZ + blockIdx.y;
 }
 
+// (x chunk, row) of this workgroup for the vector sweeps.  Workgroups are dealt to the 8 XCDs
+// round-robin in linear order (x fastest), so with the plain mapping the two x-neighbours of a
+// chunk always run on other XCDs and the cache line that a shifted 1 KiB access shares with the
+// neighbouring chunk is fetched from memory once per XCD (measured: +8 % FETCH_SIZE).  With
+// xcd_rows set, each group of 8 consecutive rows is re-dealt so that one XCD walks one whole row:
+// linear id r inside the group -> row r % 8, chunk r / 8.  Placement only affects speed, never
+// results.  Rows beyond the last full group of 8 keep the plain mapping.
+__device__ __forceinline__ void block_coords(const Geom &g, uint32_t &chunk, uint32_t &y)
+{
+    uint32_t bx = blockIdx.x;
+    uint32_t by = blockIdx.z * kRowsPerGridZ + blockIdx.y;  // row index relative to y_lo
+    const uint32_t rows = g.y_hi - g.y_lo;
+    if (g.xcd_rows && by < (rows & ~7u)) {
+        const uint32_t r = (by & 7u) * gridDim.x + bx;
+        by = (by & ~7u) + (r & 7u);
+        bx = r >> 3;
+    }
+    chunk = bx;
+    y = g.y_lo + by;
+}
+
 __device__ __forceinline__ uint32_t row_up(const Geom &g, uint32_t y)
 {
     return g.wrap_y ? ((y + 1 == g.ny) ? 0u : y + 1) : y + 1;
@@ -230,10 +252,10 @@ template <typename T, int V, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
-    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
-    if (x0 >= g.nx) return;
-    const uint32_t y = block_row(g);
-    if (y >= g.y_hi) return;
+    uint32_t chunk, y;
+    block_coords(g, chunk, y);
+    const uint32_t x0 = (chunk * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx || y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
     const uint32_t yu = row_up(g, y), yd = row_down(g, y);
     const T *r7 = rowp(f, plane, 7, yu, g.nx), *r4 = rowp(f, plane, 4, yu, g.nx), *r8 = rowp(f, plane, 8, yu, g.nx);
@@ -281,10 +303,10 @@ template <typename T, int V, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
-    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
-    if (x0 >= g.nx) return;
-    const uint32_t y = block_row(g);
-    if (y >= g.y_hi) return;
+    uint32_t chunk, y;
+    block_coords(g, chunk, y);
+    const uint32_t x0 = (chunk * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx || y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
     const uint32_t yu = row_up(g, y), yd = row_down(g, y);
     T c[9][V];
@@ -429,11 +451,11 @@ template <typename T, int V, int BLOCK, bool PULL>
 __global__ void __launch_bounds__(BLOCK)
 k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
 {
-    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * V;
-    if (x0 >= g.nx) return;
+    uint32_t chunk, y;
+    block_coords(g, chunk, y);
+    const uint32_t x0 = (chunk * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx || y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    const uint32_t y = block_row(g);
-    if (y >= g.y_hi) return;
     {
         const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
         const bool t = (yg == g.ny_glob - 1), b = (yg == 0);

@@ -154,6 +154,20 @@ class SlabSimulation:
             s_dn, s_up, r_dn, r_up = 1, n, 0, n + 1
         else:
             s_dn, s_up, r_dn, r_up = 0, n + 1, 1, n
+
+        # x range that travels, per channel.  Periodic scenes and pull: the whole row.  Lid-driven
+        # push: a population moving in -x never reaches x=nx-1 of the next row and one moving in +x
+        # never reaches x=0 (their would-be sources lie behind the side walls); those two slots of
+        # the destination row hold the bounced-back populations of the wall nodes themselves
+        # (reference pull-push.cpp:520-528) and must not be overwritten by the exchange.
+        def xs(q):
+            if pull or self.periodic:
+                return slice(None)
+            if q in (6, 7):   # cx = -1
+                return slice(0, self.nx - 1)
+            if q in (5, 8):   # cx = +1
+                return slice(1, self.nx)
+            return slice(None)
         if self.cuda:
             if self.overlap:
                 self._edges_done.record(self.compute_stream)
@@ -165,9 +179,9 @@ class SlabSimulation:
             if self.world == 1:
                 if self.lower is not None:  # periodic: the neighbour is this rank itself
                     for q in DOWN_CHANNELS:
-                        a[q, r_up].copy_(a[q, s_dn])
+                        a[q, r_up, xs(q)].copy_(a[q, s_dn, xs(q)])
                     for q in UP_CHANNELS:
-                        a[q, r_dn].copy_(a[q, s_up])
+                        a[q, r_dn, xs(q)].copy_(a[q, s_up, xs(q)])
             else:
                 # Matching between one pair of ranks is by issue order (RCCL has no tags): what I
                 # send down is what the lower rank receives "from above", so sends go [down, up] and
@@ -176,16 +190,16 @@ class SlabSimulation:
                 p2p: List[dist.P2POp] = []
                 if self.lower is not None:
                     for q in DOWN_CHANNELS:
-                        p2p.append(dist.P2POp(dist.isend, a[q, s_dn], self._peer(self.lower), self.group, tag=q))
+                        p2p.append(dist.P2POp(dist.isend, a[q, s_dn, xs(q)], self._peer(self.lower), self.group, tag=q))
                 if self.upper is not None:
                     for q in UP_CHANNELS:
-                        p2p.append(dist.P2POp(dist.isend, a[q, s_up], self._peer(self.upper), self.group, tag=q))
+                        p2p.append(dist.P2POp(dist.isend, a[q, s_up, xs(q)], self._peer(self.upper), self.group, tag=q))
                 if self.upper is not None:
                     for q in DOWN_CHANNELS:
-                        p2p.append(dist.P2POp(dist.irecv, a[q, r_up], self._peer(self.upper), self.group, tag=q))
+                        p2p.append(dist.P2POp(dist.irecv, a[q, r_up, xs(q)], self._peer(self.upper), self.group, tag=q))
                 if self.lower is not None:
                     for q in UP_CHANNELS:
-                        p2p.append(dist.P2POp(dist.irecv, a[q, r_dn], self._peer(self.lower), self.group, tag=q))
+                        p2p.append(dist.P2POp(dist.irecv, a[q, r_dn, xs(q)], self._peer(self.lower), self.group, tag=q))
                 if p2p:
                     for req in dist.batch_isend_irecv(p2p):
                         req.wait()

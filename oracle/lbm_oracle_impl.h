@@ -146,6 +146,32 @@ static inline void FN(push_node)(const FLT *f, FLT *buf, uint64_t nx, uint64_t n
     AT(buf, 5, yu, xr) = out[5];
 }
 
+/* Row kernels: the interior of a row (x in [1,nx-1)) has xl=x-1, xr=x+1 with no wrap, so it is
+ * written over plain row pointers and the compiler may vectorise it (vectorisation does not change
+ * any rounding: no reassociation, no contraction in the strict build).  The two edge nodes go
+ * through the single-node forms with wrapped indices. */
+static inline void FN(pull_row_interior)(const FLT *restrict r0, const FLT *restrict r1,
+                                         const FLT *restrict r2, const FLT *restrict r3,
+                                         const FLT *restrict r4, const FLT *restrict r5,
+                                         const FLT *restrict r6, const FLT *restrict r7,
+                                         const FLT *restrict r8, FLT *restrict const w[9],
+                                         uint64_t nx, FLT OMEGA)
+{
+    FLT *restrict w0 = w[0], *restrict w1 = w[1], *restrict w2 = w[2], *restrict w3 = w[3];
+    FLT *restrict w4 = w[4], *restrict w5 = w[5], *restrict w6 = w[6], *restrict w7 = w[7];
+    FLT *restrict w8 = w[8];
+#pragma omp simd
+    for (uint64_t x = 1; x < nx - 1; ++x) {
+        FLT in[9], out[9];
+        in[7] = r7[x + 1]; in[4] = r4[x]; in[8] = r8[x - 1];
+        in[3] = r3[x + 1]; in[0] = r0[x]; in[1] = r1[x - 1];
+        in[6] = r6[x + 1]; in[2] = r2[x]; in[5] = r5[x - 1];
+        FN(collide)(in, out, OMEGA);
+        w0[x] = out[0]; w1[x] = out[1]; w2[x] = out[2]; w3[x] = out[3]; w4[x] = out[4];
+        w5[x] = out[5]; w6[x] = out[6]; w7[x] = out[7]; w8[x] = out[8];
+    }
+}
+
 /* Rows [y_lo,y_hi) of an [9][ny][nx] array, x periodic.  wrap_y!=0: y neighbours wrap by
  * comparison (pull-push.cpp:277-280) -- with y_lo=0,y_hi=ny this is pull_periodic_no_mpi
  * (pull-push.cpp:268-288).  wrap_y==0: rows y-1 / y+1 are read as they are (halo rows present),
@@ -157,7 +183,14 @@ void FN(orc_pull_rows)(const FLT *f, FLT *buf, uint64_t nx, uint64_t ny, uint64_
     for (uint64_t y = y_lo; y < y_hi; ++y) {
         const uint64_t yu = wrap_y ? ((y + 1 == ny) ? 0 : y + 1) : y + 1;
         const uint64_t yd = wrap_y ? ((y == 0) ? ny - 1 : y - 1) : y - 1;
-        for (uint64_t x = 0; x < nx; ++x) {
+        if (nx >= 3) {
+            FLT *w[9];
+            for (unsigned q = 0; q < 9; ++q) w[q] = &AT(buf, q, y, 0);
+            FN(pull_row_interior)(&AT(f, 0, y, 0), &AT(f, 1, y, 0), &AT(f, 2, yd, 0), &AT(f, 3, y, 0),
+                                  &AT(f, 4, yu, 0), &AT(f, 5, yd, 0), &AT(f, 6, yd, 0),
+                                  &AT(f, 7, yu, 0), &AT(f, 8, yu, 0), w, nx, OMEGA);
+        }
+        for (uint64_t x = 0; x < nx; x += (nx >= 3 && x == 0) ? nx - 1 : 1) {
             const uint64_t xr = (x + 1 == nx) ? 0 : x + 1;
             const uint64_t xl = (x == 0) ? nx - 1 : x - 1;
             FN(pull_node)(f, buf, nx, ny, x, y, xl, xr, yd, yu, OMEGA);
@@ -174,7 +207,29 @@ void FN(orc_push_rows)(const FLT *f, FLT *buf, uint64_t nx, uint64_t ny, uint64_
     for (uint64_t y = y_lo; y < y_hi; ++y) {
         const uint64_t yu = wrap_y ? ((y + 1 == ny) ? 0 : y + 1) : y + 1;
         const uint64_t yd = wrap_y ? ((y == 0) ? ny - 1 : y - 1) : y - 1;
-        for (uint64_t x = 0; x < nx; ++x) {
+        if (nx >= 3) {
+            const FLT *restrict r0 = &AT(f, 0, y, 0), *restrict r1 = &AT(f, 1, y, 0);
+            const FLT *restrict r2 = &AT(f, 2, y, 0), *restrict r3 = &AT(f, 3, y, 0);
+            const FLT *restrict r4 = &AT(f, 4, y, 0), *restrict r5 = &AT(f, 5, y, 0);
+            const FLT *restrict r6 = &AT(f, 6, y, 0), *restrict r7 = &AT(f, 7, y, 0);
+            const FLT *restrict r8 = &AT(f, 8, y, 0);
+            FLT *restrict w7 = &AT(buf, 7, yd, 0), *restrict w4 = &AT(buf, 4, yd, 0);
+            FLT *restrict w8 = &AT(buf, 8, yd, 0), *restrict w3 = &AT(buf, 3, y, 0);
+            FLT *restrict w0 = &AT(buf, 0, y, 0), *restrict w1 = &AT(buf, 1, y, 0);
+            FLT *restrict w6 = &AT(buf, 6, yu, 0), *restrict w2 = &AT(buf, 2, yu, 0);
+            FLT *restrict w5 = &AT(buf, 5, yu, 0);
+#pragma omp simd
+            for (uint64_t x = 1; x < nx - 1; ++x) {
+                FLT in[9], out[9];
+                in[0] = r0[x]; in[1] = r1[x]; in[2] = r2[x]; in[3] = r3[x]; in[4] = r4[x];
+                in[5] = r5[x]; in[6] = r6[x]; in[7] = r7[x]; in[8] = r8[x];
+                FN(collide)(in, out, OMEGA);
+                w7[x - 1] = out[7]; w4[x] = out[4]; w8[x + 1] = out[8];
+                w3[x - 1] = out[3]; w0[x] = out[0]; w1[x + 1] = out[1];
+                w6[x - 1] = out[6]; w2[x] = out[2]; w5[x + 1] = out[5];
+            }
+        }
+        for (uint64_t x = 0; x < nx; x += (nx >= 3 && x == 0) ? nx - 1 : 1) {
             const uint64_t xr = (x + 1 == nx) ? 0 : x + 1;
             const uint64_t xl = (x == 0) ? nx - 1 : x - 1;
             FN(push_node)(f, buf, nx, ny, x, y, xl, xr, yd, yu, OMEGA);
