@@ -1,0 +1,359 @@
+// `lbm` command-line driver on the HIP C ABI (include/lbm_hip.h).
+//
+// Keeps the command-line surface, the text output formats and the stderr contract of the
+// reference driver (JulianKarrer/lbm src/main.cpp:31-89, :407-444; flags src/io.cpp:3-133; outputs
+// src/io.cpp:177-294) so that the upstream scripts (benchmark.py, problem-size.py, shear-wave.py,
+// shearwave-video.py, lid-driven-stationary.py) drive it unchanged:
+//   * build/main, run with cwd=build; precision chosen at build time by src/macros.h;
+//   * stdout (or -f file): -omv "<max>," per output; -ov NY lines + "#"; -ovf ux block, "#", uy
+//     block, "#"; output happens BEFORE step t when t % of == 0;
+//   * stderr: "running on<NX>x<NY>", ..., blank line, and as the LAST line
+//     "<NX*NY*STEPS> lattice updates in |<ns>|ns => <MLUPS> MLUPS".
+// All lattice arithmetic runs in the gfx950 kernels; the host only parses, launches and prints.
+#include <hip/hip_runtime.h>
+
+#include <charconv>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lbm_hip.h"
+#include "macros.h"
+
+// defaults as the reference gives them (main.cpp:12-24)
+#ifndef USE_SINGLE_PRECISION
+#define USE_SINGLE_PRECISION true
+#endif
+#ifndef UNROLL_LOOPS
+#define UNROLL_LOOPS true
+#endif
+#ifndef COALESCING
+#define COALESCING true
+#endif
+#ifndef USE_MPI
+#define USE_MPI false
+#endif
+
+#if USE_SINGLE_PRECISION
+typedef float FLT;
+#else
+typedef double FLT;
+#endif
+static const int kPrec = (int)sizeof(FLT);
+
+typedef unsigned long long UINT;  // reference global.h:32
+
+enum OutputType { NONE, MAX_VEL, VEL_MAGS, VEL_FIELD };  // reference global.h:46-55
+enum SceneType { SHEAR_WAVE, LID_DRIVEN };               // reference global.h:59-64
+
+struct Options {
+    UINT nx = 1024, ny = 1024, out_every = 0, steps = 50000, tx = 512, ty = 1;
+    double omega = 0.5, rho = 1.0, u = 0.1;
+    bool push = false;
+    OutputType output = NONE;
+    SceneType scene = SHEAR_WAVE;
+    std::string file;
+    bool use_file = false;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Command line (reference io.cpp:3-133).  Note the reference registers -tx/-ty under the long
+// names --x-grid-points/--y-grid-points a second time (io.cpp:52,58); its parser maps a name to the
+// last argument registered under it, so the long names address the tile sizes and only -nx/-ny
+// address the lattice.  That behaviour is kept.
+static const char *kUsage =
+    "Usage: lbm [--help] [--version] -nx VAR -ny VAR --output-frequency VAR --steps VAR --omega VAR "
+    "--density VAR --initial-velocity VAR --x-grid-points VAR --y-grid-points VAR [--push] "
+    "[[--output-max-vel]|[--output-velocity]|[--output-velocity-field]] [--file VAR] "
+    "[[--shear-wave-decay]|[--lid-driven-cavity]]\n\n"
+    "Optional arguments:\n"
+    "  -h, --help                    shows help message and exits \n"
+    "  -v, --version                 prints version information and exits \n"
+    "  -nx                           Specify the number of grid points in the x-direction [default: 1024]\n"
+    "  -ny                           Specify the number of grid points in the y-direction [default: 1024]\n"
+    "  -of, --output-frequency       Specify how frequently (as an integer number of timesteps) simulation results should be output. 0 means no output. [default: 0]\n"
+    "  -s, --steps                   Specify the total number of simulation time steps to run [default: 50000]\n"
+    "  -w, --omega                   Specify the relaxation coefficient omega, which should obey be a float in (0;2) [default: 0.5]\n"
+    "  -rho, --density               Specify the initial density at each fluid node [default: 1]\n"
+    "  -u, --initial-velocity        Specify the initial velocity. For the shear wave decay, this is the velocity amplitude. For the lid-driven cavity, this is the horizontal velocity of the top lid wall. [default: 0.1]\n"
+    "  -tx, --x-grid-points          Specify the kernel tiling size in x-direction for performance optimization [default: 512]\n"
+    "  -ty, --y-grid-points          Specify the kernel tiling size in y-direction for performance optimization [default: 1]\n"
+    "  -push, --push                 Specify whether to prefer a push-type streaming pattern over pull-type. Pulling is used by default. \n"
+    "  -omv, --output-max-vel        If specified, the program outputs the maximum velocity magnitude as a comma-seperated list of floats with a trailing comma \n"
+    "  -ov, --output-velocity        If specified, the program outputs the velocity magnitude at each node as #-seperated CSV tables of NY columns and NX rows \n"
+    "  -ovf, --output-velocity-field If specified, the program outputs the components of the velocity field at each node as #-seperated CSV tables of NY columns and NX rows, first all x-components, then all y-components \n"
+    "  -f, --file                    Specify a filename to write to instead of printing output to std::cout \n"
+    "  -sw, --shear-wave-decay       Simulate a shear-wave decay with velocities in x-direction and periodic boundaries. This is the default. \n"
+    "  -ld, --lid-driven-cavity      Simulate a lid driven cavity with bounce-back solid walls and a moving wall at the top, where the fluid is initially at rest. \n";
+
+static UINT parse_uint(const std::string &s)
+{
+    UINT x = 0;
+    const char *first = s.data(), *last = s.data() + s.size();
+    auto [ptr, ec] = std::from_chars(first, last, x, 10);
+    if (ec == std::errc()) {
+        if (ptr == last) return x;
+        throw std::invalid_argument("pattern '" + s + "' does not match to the end");
+    }
+    if (ec == std::errc::invalid_argument) throw std::invalid_argument("pattern '" + s + "' not found");
+    throw std::range_error("'" + s + "' not representable");
+}
+
+static double parse_double(const std::string &s)
+{
+    if (s.empty()) throw std::invalid_argument("pattern '" + s + "' not found");
+    char *end = nullptr;
+    const double v = std::strtod(s.c_str(), &end);
+    if (end == s.c_str()) throw std::invalid_argument("pattern '" + s + "' not found");
+    if (*end != '\0') throw std::invalid_argument("pattern '" + s + "' does not match to the end");
+    return v;
+}
+
+static bool looks_like_option(const std::string &s)
+{
+    // a token starting with '-' that is not a (negative) number is an option name
+    if (s.size() < 2 || s[0] != '-') return false;
+    char *end = nullptr;
+    std::strtod(s.c_str(), &end);
+    return !(end != s.c_str() && *end == '\0');
+}
+
+static Options parse_args(int argc, char **argv)
+{
+    Options o;
+    std::string first_output, first_scene;  // full names of the first flag used in an exclusive group
+    auto exclusive = [](std::string &first, const char *full) {
+        if (!first.empty() && first != full)
+            throw std::runtime_error(std::string("Argument '") + full + "' not allowed with '" + first + "'");
+        first = full;
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&]() -> std::string {
+            if (i + 1 >= argc || looks_like_option(argv[i + 1]))
+                throw std::runtime_error("Too few arguments for '" + a + "'.");
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") {
+            std::cout << kUsage;
+            std::exit(0);
+        } else if (a == "-v" || a == "--version") {
+            std::cout << "1.0" << std::endl;
+            std::exit(0);
+        } else if (a == "-nx") o.nx = parse_uint(value());
+        else if (a == "-ny") o.ny = parse_uint(value());
+        else if (a == "-of" || a == "--output-frequency") o.out_every = parse_uint(value());
+        else if (a == "-s" || a == "--steps") o.steps = parse_uint(value());
+        else if (a == "-w" || a == "--omega") o.omega = parse_double(value());
+        else if (a == "-rho" || a == "--density") o.rho = parse_double(value());
+        else if (a == "-u" || a == "--initial-velocity") o.u = parse_double(value());
+        else if (a == "-tx" || a == "--x-grid-points") o.tx = parse_uint(value());
+        else if (a == "-ty" || a == "--y-grid-points") o.ty = parse_uint(value());
+        else if (a == "-push" || a == "--push") o.push = true;
+        else if (a == "-omv" || a == "--output-max-vel") { exclusive(first_output, "-omv/--output-max-vel"); o.output = MAX_VEL; }
+        else if (a == "-ov" || a == "--output-velocity") { exclusive(first_output, "-ov/--output-velocity"); o.output = VEL_MAGS; }
+        else if (a == "-ovf" || a == "--output-velocity-field") { exclusive(first_output, "-ovf/--output-velocity-field"); o.output = VEL_FIELD; }
+        else if (a == "-f" || a == "--file") { o.file = value(); o.use_file = true; }
+        else if (a == "-sw" || a == "--shear-wave-decay") { exclusive(first_scene, "-sw/--shear-wave-decay"); o.scene = SHEAR_WAVE; }
+        else if (a == "-ld" || a == "--lid-driven-cavity") { exclusive(first_scene, "-ld/--lid-driven-cavity"); o.scene = LID_DRIVEN; }
+        else throw std::runtime_error("Unknown argument: " + a);
+    }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void die_hip(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        std::cerr << what << ": " << hipGetErrorString(e) << std::endl;
+        std::exit(1);
+    }
+}
+static void die_lbm(int status, const char *what)
+{
+    if (status != LBM_OK) {
+        std::cerr << what << ": " << lbm_status_string(status) << ": " << lbm_last_error() << std::endl;
+        std::exit(1);
+    }
+}
+
+// C++ stream formatting of a float/double at default precision (what the reference's operator<<
+// produces): %g with 6 significant digits.
+static inline int fmt_g(char *dst, size_t cap, FLT v) { return std::snprintf(dst, cap, "%g", (double)v); }
+
+// NY lines (y=0 first) of NX comma-separated values, then "#" (io.cpp:234-254, :268-286).
+// check_nan: the -ov path stops at the first NaN, having already printed what precedes it.
+static bool write_block(std::ostream &os, const FLT *a, UINT nx, UINT ny, bool check_nan)
+{
+    std::string line;
+    char tmp[64];
+    for (UINT y = 0; y < ny; ++y) {
+        line.clear();
+        for (UINT x = 0; x < nx; ++x) {
+            const FLT v = a[y * nx + x];
+            if (check_nan && v != v) {
+                os << line;
+                std::cerr << "NaN encountered at x=" << x << " y=" << y << std::endl;
+                return false;
+            }
+            line.append(tmp, (size_t)fmt_g(tmp, sizeof tmp, v));
+            if (x < nx - 1) line.push_back(',');
+        }
+        line.push_back('\n');
+        os << line;
+    }
+    os << "#" << std::endl;
+    return true;
+}
+
+struct Run {
+    Options o;
+    std::ostream *out = &std::cout;
+    std::ofstream file;
+    void *f = nullptr, *buf = nullptr, *vel = nullptr;
+    std::vector<FLT> host;
+    hipStream_t stream = nullptr;
+    long long sweep_ns = 0;  // time spent in the steps alone (reported before the final line)
+};
+
+// output() of io.cpp:177-294
+static bool output(Run &r)
+{
+    const Options &o = r.o;
+    switch (o.output) {
+        case MAX_VEL: {
+            double m = 0;
+            die_lbm(lbm_max_velocity(r.f, kPrec, o.nx, o.ny, 0, o.ny, r.stream, &m), "max velocity");
+            char tmp[64];
+            fmt_g(tmp, sizeof tmp, (FLT)m);
+            (*r.out) << tmp << "," << std::flush;
+        } break;
+        case VEL_MAGS: {
+            die_lbm(lbm_velocity_magnitudes(r.f, r.vel, kPrec, o.nx, o.ny, 0, o.ny, r.stream), "velocity magnitudes");
+            r.host.resize((size_t)o.nx * o.ny);
+            die_hip(hipMemcpyAsync(r.host.data(), r.vel, r.host.size() * sizeof(FLT), hipMemcpyDeviceToHost, r.stream), "copy");
+            die_hip(hipStreamSynchronize(r.stream), "sync");
+            if (!write_block(*r.out, r.host.data(), o.nx, o.ny, true)) return false;
+        } break;
+        case VEL_FIELD: {
+            die_lbm(lbm_compute_velocities(r.f, r.vel, kPrec, o.nx, o.ny, 0, o.ny, r.stream), "velocities");
+            r.host.resize((size_t)2 * o.nx * o.ny);
+            die_hip(hipMemcpyAsync(r.host.data(), r.vel, r.host.size() * sizeof(FLT), hipMemcpyDeviceToHost, r.stream), "copy");
+            die_hip(hipStreamSynchronize(r.stream), "sync");
+            write_block(*r.out, r.host.data(), o.nx, o.ny, false);
+            write_block(*r.out, r.host.data() + (size_t)o.nx * o.ny, o.nx, o.ny, false);
+        } break;
+        default: break;
+    }
+    return true;
+}
+
+// run_simulation_single_node of main.cpp:31-89
+static bool run_simulation(Run &r)
+{
+    const Options &o = r.o;
+    const size_t bytes = (size_t)9 * o.nx * o.ny * sizeof(FLT);
+    die_hip(hipMalloc(&r.f, bytes), "allocating f");
+    die_hip(hipMalloc(&r.buf, bytes), "allocating buf");
+    if (o.output == VEL_MAGS || o.output == VEL_FIELD)
+        die_hip(hipMalloc(&r.vel, (size_t)2 * o.nx * o.ny * sizeof(FLT)), "allocating vel");
+
+    std::cerr << "running on" << o.nx << "x" << o.ny << std::endl;
+
+    // -tx/-ty are the reference's MDRange tile; here -tx is the workgroup-width hint (kept only
+    // when it names a supported width) and -ty is ignored
+    if (o.tx == 64 || o.tx == 128 || o.tx == 256) lbm_set_launch_shape((unsigned)o.tx, 0);
+
+    if (o.scene == LID_DRIVEN) die_lbm(lbm_init_rest(r.f, kPrec, o.nx, o.ny, o.rho, r.stream), "init_rest");
+    else die_lbm(lbm_init_shearwave(r.f, kPrec, o.nx, o.ny, o.rho, o.u, 0, o.ny, 0, r.stream), "init_shearwave");
+
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (UINT t = 0; t < o.steps; ++t) {
+        if (o.out_every > 0 && t % o.out_every == 0) {
+            if (!output(r)) return false;
+        }
+        int s;
+        if (o.scene == LID_DRIVEN) {
+            // the reference's lid scene always pushes (main.cpp:72-74); -push is ignored there too
+            s = lbm_push_lid_driven(r.f, r.buf, kPrec, o.nx, o.ny, o.omega, o.rho, o.u, r.stream);
+        } else {
+            s = o.push ? lbm_push_periodic_no_mpi(r.f, r.buf, kPrec, o.nx, o.ny, o.omega, r.stream)
+                       : lbm_pull_periodic_no_mpi(r.f, r.buf, kPrec, o.nx, o.ny, o.omega, r.stream);
+        }
+        die_lbm(s, "sweep");
+        std::swap(r.f, r.buf);
+    }
+    die_hip(hipStreamSynchronize(r.stream), "sync");
+    r.sweep_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return true;
+}
+
+int main(int argc, char *argv[])
+{
+#if USE_MPI
+    std::cerr << "note: USE_MPI is set in src/macros.h; this driver runs one GPU per process and has no MPI path "
+                 "(multi-GPU runs use the y-slab decomposition of the lbm_amd package)" << std::endl;
+#endif
+#if !COALESCING
+    std::cerr << "note: COALESCING=false (array-of-structures storage) is not available; running with the "
+                 "structure-of-arrays layout" << std::endl;
+#endif
+    Run r;
+    try {
+        r.o = parse_args(argc, argv);
+        if (r.o.use_file) {
+            r.file.open(r.o.file);
+            if (!r.file.is_open()) {
+                std::cerr << "Failed to open file: " << r.o.file << "\n";
+                std::exit(1);
+            }
+            r.out = &r.file;
+        }
+    } catch (const std::exception &err) {
+        std::cerr << err.what() << std::endl;
+        std::cerr << kUsage;
+        std::exit(1);
+    }
+    if (r.o.nx == 0 || r.o.ny == 0) {
+        std::cerr << "lattice extents must be positive" << std::endl;
+        return 1;
+    }
+
+    // runtime start-up happens before the clock starts, where the reference has Kokkos::initialize
+    // (main.cpp:417-421)
+    die_hip(hipSetDevice(0), "hipSetDevice");
+    die_hip(hipFree(nullptr), "HIP runtime start-up");
+    die_hip(hipStreamCreate(&r.stream), "stream");
+
+    const auto start = std::chrono::high_resolution_clock::now();
+    const bool success = run_simulation(r);
+    // the reference stops its clock without a fence (main.cpp:428); here every kernel has finished
+    die_hip(hipDeviceSynchronize(), "sync");
+    const auto end = std::chrono::high_resolution_clock::now();
+    const UINT span = (UINT)std::chrono::duration_cast<std::chrono::nanoseconds>(end - start).count();
+
+    const Options &o = r.o;
+    if (success && r.sweep_ns > 0 && o.steps > 0) {
+        const double mlups = (double)o.nx * (double)o.ny * (double)o.steps * 1000.0 / (double)r.sweep_ns;
+        const double gbs = mlups * 1e-3 * 18.0 * sizeof(FLT);
+        std::cerr << "time loop only (without allocation and initialisation): |" << r.sweep_ns << "|ns => "
+                  << (UINT)mlups << " MLUPS, " << (UINT)gbs << " GB/s algorithmic = "
+                  << (int)(gbs / 80.0 + 0.5) << " % of the 8 TB/s HBM peak" << std::endl;
+    }
+    const UINT mlups = span ? (o.nx * o.ny * o.steps * 1000) / span : 0;
+    std::cerr << std::endl
+              << o.nx * o.ny * o.steps << " lattice updates in |" << span << "|ns => " << mlups << " MLUPS"
+              << std::endl;
+    (*r.out) << std::flush;
+    (void)hipFree(r.f);
+    (void)hipFree(r.buf);
+    if (r.vel) (void)hipFree(r.vel);
+    return success ? 0 : 1;
+}

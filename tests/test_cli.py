@@ -1,0 +1,116 @@
+"""The `lbm` command-line driver (build/main): flag surface, text formats, stderr contract.
+
+What the upstream scripts rely on (reference benchmark.py:30-38, shear-wave.py:60-64,
+shearwave-video.py:26-32, lid-driven-stationary.py:41-57): the binary is build/main, run with
+cwd=build; results go to stdout or the -f file; the LAST stderr line carries the nanoseconds
+between the last two '|'."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build")
+MAIN = os.path.join(BUILD, "main")
+
+
+def run_main(*args, check=True):
+    if not os.path.exists(MAIN):
+        pytest.fail("build/main is missing: run `python __graft_entry__.py` (cmake target `main`) first")
+    p = subprocess.run(["./main", *map(str, args)], cwd=BUILD, capture_output=True, text=True, timeout=600)
+    if check:
+        assert p.returncode == 0, p.stderr
+    return p
+
+
+# ---- no GPU needed: parsing happens before any device call -----------------------------------
+def test_version_and_help():
+    assert run_main("--version").stdout.strip() == "1.0"
+    assert run_main("-v").stdout.strip() == "1.0"
+    h = run_main("--help").stdout
+    for flag in ("-nx", "-ny", "-of", "--output-frequency", "-s", "--steps", "-w", "--omega", "-rho", "--density",
+                 "-u", "--initial-velocity", "-tx", "-ty", "-push", "--push", "-omv", "--output-max-vel", "-ov",
+                 "--output-velocity", "-ovf", "--output-velocity-field", "-f", "--file", "-sw",
+                 "--shear-wave-decay", "-ld", "--lid-driven-cavity"):
+        assert flag in h, flag
+
+
+def test_parse_errors_print_message_and_usage_and_exit_1():
+    p = run_main("-omv", "-ov", check=False)
+    assert p.returncode == 1
+    assert p.stderr.startswith("Argument '-ov/--output-velocity' not allowed with '-omv/--output-max-vel'\n")
+    assert "Usage: lbm" in p.stderr
+    p = run_main("-nx", "abc", check=False)
+    assert p.returncode == 1 and p.stderr.startswith("pattern 'abc' not found\n")
+    p = run_main("-sw", "-ld", check=False)
+    assert p.returncode == 1 and "not allowed with '-sw/--shear-wave-decay'" in p.stderr
+    p = run_main("--bogus", check=False)
+    assert p.returncode == 1 and p.stderr.startswith("Unknown argument: --bogus\n")
+    p = run_main("-nx", check=False)
+    assert p.returncode == 1 and p.stderr.startswith("Too few arguments for '-nx'.")
+    p = run_main("-f", "/nonexistent-dir/out.csv", "-s", "1", check=False)
+    assert p.returncode == 1 and p.stderr.startswith("Failed to open file: /nonexistent-dir/out.csv")
+
+
+# ---- on the GPU ---------------------------------------------------------------------------------
+LAST_LINE = re.compile(r"^(\d+) lattice updates in \|(\d+)\|ns => (\d+) MLUPS$")
+
+
+def check_stderr_contract(stderr, nx, ny, steps):
+    lines = stderr.split("\n")
+    assert lines[-1] == "" and lines[0] == f"running on{nx}x{ny}"
+    m = LAST_LINE.match(lines[-2])
+    assert m, lines[-3:]
+    assert lines[-3] == ""                      # the blank line the reference prints before it
+    assert int(m.group(1)) == nx * ny * steps
+    ns = int(stderr.split("|")[-2])             # how benchmark.py:37 extracts it
+    assert ns == int(m.group(2)) and ns > 0
+    assert int(m.group(3)) == (nx * ny * steps * 1000) // ns
+
+
+@pytest.mark.gpu
+def test_omv_series_and_stderr_contract():
+    p = run_main("-nx", 64, "-ny", 64, "-w", 0.5, "-s", 2001, "-of", 500, "-omv")
+    _, s = orc.run("shear", "pull", 64, 64, 2001, 0.5, np.float32, out_every=500)
+    assert p.stdout == "".join(orc.fmt(v) + "," for v in s)
+    check_stderr_contract(p.stderr, 64, 64, 2001)
+    # the long names address the tile sizes, only -nx/-ny the lattice (reference io.cpp:52,58)
+    p = run_main("--x-grid-points", 8, "-ny", 8, "-s", 1)
+    assert p.stderr.startswith("running on1024x8\n")
+
+
+@pytest.mark.gpu
+def test_push_flag_and_benchmark_command_shape():
+    p = run_main("-nx", 256, "-ny", 128, "-of", 0, "-s", 100, "--shear-wave-decay", "-push")
+    assert p.stdout == ""
+    check_stderr_contract(p.stderr, 256, 128, 100)
+    p = run_main("-nx", 96, "-ny", 40, "-w", 1.0, "-s", 301, "-of", 100, "-omv", "-push")
+    _, s = orc.run("shear", "push", 96, 40, 301, 1.0, np.float32, out_every=100)
+    assert p.stdout == "".join(orc.fmt(v) + "," for v in s)
+
+
+@pytest.mark.gpu
+def test_ov_and_ovf_blocks(tmp_path):
+    p = run_main("-nx", 4, "-ny", 6, "-s", 1, "-of", 1, "-ov")
+    f = orc.alloc(4, 6, np.float32)
+    orc.init_shearwave(f, np.float32(1), np.float32(0.1))
+    want = "\n".join(",".join(orc.fmt(v) for v in r) for r in orc.velocity_magnitudes(f)) + "\n#\n"
+    assert p.stdout == want
+    assert p.stdout.splitlines()[1] == "0.0866025,0.0866025,0.0866025,0.0866025"
+    # lid-driven cavity, velocity field into a file, as lid-driven-stationary.py:41-54 calls it
+    out = tmp_path / "vel.csv"
+    p = run_main("-w", 1.7, "-nx", 24, "-ny", 16, "-of", 20, "-s", 41, "-ovf", "-ld", "-u", 0.1, "-rho", 1.0, "-f", out)
+    assert p.stdout == ""
+    want = ""
+    for t in (0, 20, 40):
+        fr, _ = orc.run("lid", "push", 24, 16, t, 1.7, np.float32)
+        vel = orc.compute_velocities(fr)
+        for c in range(2):
+            want += "\n".join(",".join(orc.fmt(v) for v in r) for r in vel[c]) + "\n#\n"
+    assert out.read_text() == want
+    blocks = out.read_text().split("#")          # how the upstream scripts split frames
+    assert len(blocks) == 7
