@@ -1,0 +1,99 @@
+"""Parity at the benchmark's full lattice sizes, through properties that make a small oracle run
+speak for the large GPU run.
+
+* Shear wave: the initial state and every update are x-invariant, so column x of the 16384 x 16384
+  GPU state must equal, bit for bit, the oracle's state on an 8 x 16384 lattice (same NY, tiny NX).
+* Lid-driven cavity: information travels one node per step, so after t steps everything within the
+  t-neighbourhood of a corner equals the same corner region of a small cavity, the band under the lid
+  away from the side walls is x-invariant and equals the small cavity's mid columns, and the deep
+  interior is still uniform.
+* Mass is conserved; pull and push give the same velocities to rounding.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TORCH = {np.float32: torch.float32, np.float64: torch.float64}
+
+
+def _free():
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+def test_shear_wave_16384sq_fp32_equals_narrow_oracle(scheme):
+    from lbm_amd import Simulation
+    nx = ny = 16384
+    steps, omega = 12, 0.5
+    sim = Simulation(nx, ny, scene="shear", scheme=scheme, dtype=torch.float32, omega=omega)
+    sim.step(steps)
+    want, _ = orc.run("shear", scheme, 8, ny, steps, omega, np.float32)
+    col = torch.from_numpy(np.ascontiguousarray(want[:, :, :1])).cuda()          # [9, NY, 1]
+    # every column equals the oracle's column (also proves exact x-invariance across 16384 columns)
+    assert bool((sim.f.view(torch.int32) == col.view(torch.int32)).all())
+    assert sim.max_velocity() == float(orc.max_velocity(want))
+    total = float(sim.f.sum(dtype=torch.float64))
+    assert abs(total - nx * ny) / (nx * ny) < 1e-6
+    del sim
+    _free()
+
+
+def test_shear_wave_32768x4096_fp32_pull_equals_narrow_oracle():
+    """The per-GPU slab shape of the multi-GPU configuration (row length 32768)."""
+    from lbm_amd import Simulation
+    nx, ny, steps, omega = 32768, 4096, 10, 1.0
+    sim = Simulation(nx, ny, scene="shear", scheme="pull", dtype=torch.float32, omega=omega)
+    sim.step(steps)
+    want, _ = orc.run("shear", "pull", 8, ny, steps, omega, np.float32)
+    col = torch.from_numpy(np.ascontiguousarray(want[:, :, :1])).cuda()
+    assert bool((sim.f.view(torch.int32) == col.view(torch.int32)).all())
+    del sim
+    _free()
+
+
+@pytest.mark.parametrize("scheme", ["push", "pull"])
+def test_lid_cavity_16384sq_fp64_corners_and_bands_equal_small_cavity(scheme):
+    from lbm_amd import Simulation
+    n, m, t, omega = 16384, 192, 24, 1.0
+    sim = Simulation(n, n, scene="lid", scheme=scheme, dtype=torch.float64, omega=omega, u=0.1)
+    sim.step(t)
+    small, _ = orc.run("lid", scheme, m, m, t, omega, np.float64)
+    w = 2 * t + 8                      # region certainly inside the corner's domain of dependence
+    assert w < m // 2
+    big = sim.f
+    def eq(a, b):
+        return np.array_equal(a.cpu().numpy().view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+    assert eq(big[:, :w, :w], small[:, :w, :w])                # bottom-left corner
+    assert eq(big[:, :w, n - w:], small[:, :w, m - w:])        # bottom-right
+    assert eq(big[:, n - w:, :w], small[:, m - w:, :w])        # top-left (lid)
+    assert eq(big[:, n - w:, n - w:], small[:, m - w:, m - w:])  # top-right (lid)
+    # band under the lid, far from the side walls: x-invariant, equal to the small cavity's mid column
+    mid = small[:, m - w:, m // 2:m // 2 + 1]
+    band = big[:, n - w:, 4096:12288]
+    assert bool((band.view(torch.int64) == torch.from_numpy(np.ascontiguousarray(mid)).cuda().view(torch.int64)).all())
+    # deep interior: still the uniform state every untouched node has
+    core = big[:, 1024:15360, 1024:15360]
+    ref = small[:, m // 2, m // 2].reshape(9, 1, 1)
+    assert bool((core.view(torch.int64) == torch.from_numpy(np.ascontiguousarray(ref)).cuda().view(torch.int64)).all())
+    total = float(big.sum(dtype=torch.float64))
+    assert abs(total - n * n) / (n * n) < 1e-12
+    vmax = sim.max_velocity()
+    assert vmax == float(orc.max_velocity(small))              # the extremum sits under the lid
+    del sim, big, band, core
+    _free()
+
+
+def test_pull_and_push_velocities_agree_at_full_size():
+    from lbm_amd import Simulation
+    nx = ny = 8192
+    a = Simulation(nx, ny, scene="shear", scheme="pull", dtype=torch.float32, omega=0.8)
+    b = Simulation(nx, ny, scene="shear", scheme="push", dtype=torch.float32, omega=0.8)
+    a.step(50); b.step(50)
+    va, vb = a.velocities().clone(), b.velocities()
+    assert float((va - vb).abs().max()) < 5e-7
+    del a, b, va, vb
+    _free()
