@@ -52,8 +52,9 @@ unsigned g_waves_per_cu = 0;
 // Residency is capped by giving every workgroup an unused dynamic-LDS allocation of
 // 160 KiB / (workgroups per CU).
 constexpr unsigned kDefaultThreadsX = 64;
-constexpr unsigned kDefaultWavesPerCU_f32 = 6;  // top of the plateau for fp32 (4096^2 .. 32768x8192)
-constexpr unsigned kDefaultWavesPerCU_f64 = 5;  // fp64: 4 is best by 1 % but sits on the cliff to 3
+constexpr unsigned kWavesPerCU_f32 = 6;       // top of the plateau for fp32 pull and push (4096^2 .. 32768x8192)
+constexpr unsigned kWavesPerCU_f64_pull = 5;  // fp64 pull: 4 is best by 1 % but sits on the cliff to 3
+constexpr unsigned kWavesPerCU_f64_push = 6;  // fp64 push (aligned-store form): 6 beats 5 by 4 %
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr size_t kMaxDynamicLds = 64 * 1024;
 
@@ -128,10 +129,10 @@ dim3 sweep_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
 }
 
 // Dynamic-LDS bytes per workgroup that leave room for `waves` resident waves per CU.
-size_t residency_ballast(unsigned block, size_t elem_size)
+size_t residency_ballast(unsigned block, size_t elem_size, bool pull)
 {
     const unsigned waves = g_waves_per_cu ? g_waves_per_cu
-                                          : (elem_size == 4 ? kDefaultWavesPerCU_f32 : kDefaultWavesPerCU_f64);
+                           : (elem_size == 4 ? kWavesPerCU_f32 : (pull ? kWavesPerCU_f64_pull : kWavesPerCU_f64_push));
     const unsigned waves_per_block = block / 64;
     unsigned blocks_per_cu = waves / waves_per_block;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -199,7 +200,7 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block, sizeof(T));
+        const size_t lds = residency_ballast(block, sizeof(T), PULL);
         LBM_FOR_BLOCK(block,
             if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
             else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
@@ -300,7 +301,7 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block, sizeof(T));
+        const size_t lds = residency_ballast(block, sizeof(T), PULL);
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {

@@ -296,9 +296,16 @@ k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 }
 
 // PERIODIC PUSH, vector form.  Replaces "push periodic" (pull-push.cpp:246-266) and push_periodic
-// (:124-186): aligned reads of the node's own nine populations, shifted writes.  The first and
-// last lane of a row scatter element-wise (their shifted stores would leave the row); every other
-// lane issues nine vector stores with no branch between them.
+// (:124-186).  A plain push writes the six x-moving populations shifted by one element, i.e. with
+// 16-byte stores that straddle cache lines and leave the first and last line of every 1 KiB chunk
+// half written by two different waves; measured, those partial lines cost 9 % against the pull
+// sweep although the byte counts are equal.  Here every store is a whole aligned vector instead:
+//   * each lane relaxes its V nodes and hands the value that crosses into the neighbouring lane's
+//     vector over with a wavefront shuffle;
+//   * the value that crosses into the wave from outside comes from a halo node: lane 0 also
+//     relaxes the node left of the chunk, the last lane the node right of it (periodic in x), so
+//     a wave writes exactly the lines it owns.  The two halo nodes cost 9 dword loads by two lanes
+//     and one extra pass of the relaxation arithmetic.
 template <typename T, int V, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
@@ -309,9 +316,27 @@ k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
     if (x0 >= g.nx || y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
     const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const bool first = (lane == 0);                              // left end of this wave's chunk
+    const bool last = (lane == kWave - 1) || (x0 + V == g.nx);   // right end (or end of the row)
+    const T *rq[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) rq[q] = rowp(f, plane, q, y, g.nx);
     T c[9][V];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
+    for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rq[q] + x0);
+    // halo node of this lane (wrap by comparison, pull-push.cpp:255-256); a wave with a single
+    // active lane needs both and takes the right-hand one in a second pass
+    const uint32_t hx_left = (x0 == 0) ? g.nx - 1 : x0 - 1;
+    const uint32_t hx_right = (x0 + V == g.nx) ? 0u : x0 + V;
+    T h[9], ho[9], ho2[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { h[q] = T(0); ho[q] = T(0); ho2[q] = T(0); }
+    if (first || last) {
+        const uint32_t hx = first ? hx_left : hx_right;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) h[q] = rq[q][hx];
+    }
     T o[9][V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -321,31 +346,38 @@ k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
     }
-    // scatter: pull-push.cpp:175-185
-    T *w7 = rowp(buf, plane, 7, yd, g.nx), *w4 = rowp(buf, plane, 4, yd, g.nx), *w8 = rowp(buf, plane, 8, yd, g.nx);
-    T *w3 = rowp(buf, plane, 3, y, g.nx), *w0 = rowp(buf, plane, 0, y, g.nx), *w1 = rowp(buf, plane, 1, y, g.nx);
-    T *w6 = rowp(buf, plane, 6, yu, g.nx), *w2 = rowp(buf, plane, 2, yu, g.nx), *w5 = rowp(buf, plane, 5, yu, g.nx);
-    if (x0 != 0 && x0 + V != g.nx) {
-        store_u<T, V>(w7 + (x0 - 1), o[7]);
-        store_a<T, V>(w4 + x0, o[4]);
-        store_u<T, V>(w8 + (x0 + 1), o[8]);
-        store_u<T, V>(w3 + (x0 - 1), o[3]);
-        store_a<T, V>(w0 + x0, o[0]);
-        store_u<T, V>(w1 + (x0 + 1), o[1]);
-        store_u<T, V>(w6 + (x0 - 1), o[6]);
-        store_a<T, V>(w2 + x0, o[2]);
-        store_u<T, V>(w5 + (x0 + 1), o[5]);
-    } else {
-        store_to_left<T, V>(w7, x0, g.nx, o[7]);
-        store_a<T, V>(w4 + x0, o[4]);
-        store_to_right<T, V>(w8, x0, g.nx, o[8]);
-        store_to_left<T, V>(w3, x0, g.nx, o[3]);
-        store_a<T, V>(w0 + x0, o[0]);
-        store_to_right<T, V>(w1, x0, g.nx, o[1]);
-        store_to_left<T, V>(w6, x0, g.nx, o[6]);
-        store_a<T, V>(w2 + x0, o[2]);
-        store_to_right<T, V>(w5, x0, g.nx, o[5]);
+    if (first || last) collide<T>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
+    if (first && last) {
+        T h2[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) h2[q] = rq[q][hx_right];
+        collide<T>(h2[0], h2[1], h2[2], h2[3], h2[4], h2[5], h2[6], h2[7], h2[8], om, ho2);
     }
+    // destination vectors at [x0, x0+V): +x movers take their first element from the lane to the
+    // left (or the left halo), -x movers their last element from the lane to the right (or the
+    // right halo).  pull-push.cpp:175-185 names the targets.
+    auto from_left = [&](int q, T (&d)[V]) {
+        const T nb = __shfl_up(o[q][V - 1], 1, kWave);
+        d[0] = first ? ho[q] : nb;
+#pragma unroll
+        for (int i = 1; i < V; ++i) d[i] = o[q][i - 1];
+    };
+    auto from_right = [&](int q, T (&d)[V]) {
+        const T nb = __shfl_down(o[q][0], 1, kWave);
+        d[V - 1] = last ? (first ? ho2[q] : ho[q]) : nb;
+#pragma unroll
+        for (int i = 0; i < V - 1; ++i) d[i] = o[q][i + 1];
+    };
+    T d[V];
+    from_right(7, d); store_a<T, V>(rowp(buf, plane, 7, yd, g.nx) + x0, d);
+    store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
+    from_left(8, d);  store_a<T, V>(rowp(buf, plane, 8, yd, g.nx) + x0, d);
+    from_right(3, d); store_a<T, V>(rowp(buf, plane, 3, y, g.nx) + x0, d);
+    store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
+    from_left(1, d);  store_a<T, V>(rowp(buf, plane, 1, y, g.nx) + x0, d);
+    from_right(6, d); store_a<T, V>(rowp(buf, plane, 6, yu, g.nx) + x0, d);
+    store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
+    from_left(5, d);  store_a<T, V>(rowp(buf, plane, 5, yu, g.nx) + x0, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -392,8 +424,33 @@ __device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict
     rowp(buf, plane, 5, yu, nx)[xr] = o[5];
 }
 
-// One node of push_lid_driven: pull-push.cpp:436-528.  l/r/t/b: the node touches the left /
-// right / top (lid) / bottom wall.  df = rho_eq*u_lid/6 (:518), applied only where t.
+// Streaming part of one node of push_lid_driven: pull-push.cpp:496-528.  l/r/t/b: the node touches
+// the left / right / top (lid) / bottom wall.  df = rho_eq*u_lid/6 (:518), applied only where t.
+// Targets whose x lies outside [x_min, x_max] are skipped (the caller's neighbour lane writes them).
+template <typename T>
+__device__ __forceinline__ void lid_push_scatter(T *__restrict__ buf, size_t plane, uint32_t nx,
+                                                 uint32_t x, uint32_t y, bool l, bool r, bool t, bool b,
+                                                 const T (&o)[9], T df_lid, uint32_t x_min, uint32_t x_max)
+{
+    const bool lb = l || b, lt = l || t, rb = r || b, rt = r || t;
+    const uint32_t xl = l ? x : x - 1, xr = r ? x : x + 1;
+    const uint32_t yu = t ? y : y + 1, yd = b ? y : y - 1;
+    const T df = t ? df_lid : T(0.);
+    auto put = [&](int q, uint32_t yy, uint32_t xx, T v) {
+        if (xx >= x_min && xx <= x_max) rowp(buf, plane, q, yy, nx)[xx] = v;
+    };
+    put(lb ? 5 : 7, lb ? y : yd, lb ? x : xl, o[7]);
+    put(l ? 1 : 3, y, xl, o[3]);
+    put(lt ? 8 : 6, lt ? y : yu, lt ? x : xl, o[6] + df);
+    put(b ? 2 : 4, yd, x, o[4]);
+    put(0, y, x, o[0]);
+    put(t ? 4 : 2, yu, x, o[2]);
+    put(rb ? 6 : 8, rb ? y : yd, rb ? x : xr, o[8]);
+    put(r ? 3 : 1, y, xr, o[1]);
+    put(rt ? 7 : 5, rt ? y : yu, rt ? x : xr, o[5] - df);
+}
+
+// One node of push_lid_driven: pull-push.cpp:436-528.
 template <typename T>
 __device__ __forceinline__ void lid_push_node(const T *__restrict__ f, T *__restrict__ buf,
                                               size_t plane, uint32_t nx, uint32_t x, uint32_t y,
@@ -404,19 +461,7 @@ __device__ __forceinline__ void lid_push_node(const T *__restrict__ f, T *__rest
     for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
     T o[9];
     collide<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
-    const bool lb = l || b, lt = l || t, rb = r || b, rt = r || t;
-    const uint32_t xl = l ? x : x - 1, xr = r ? x : x + 1;
-    const uint32_t yu = t ? y : y + 1, yd = b ? y : y - 1;
-    const T df = t ? df_lid : T(0.);
-    rowp(buf, plane, lb ? 5 : 7, lb ? y : yd, nx)[lb ? x : xl] = o[7];
-    rowp(buf, plane, l ? 1 : 3, y, nx)[xl] = o[3];
-    rowp(buf, plane, lt ? 8 : 6, lt ? y : yu, nx)[lt ? x : xl] = o[6] + df;
-    rowp(buf, plane, b ? 2 : 4, yd, nx)[x] = o[4];
-    rowp(buf, plane, 0, y, nx)[x] = o[0];
-    rowp(buf, plane, t ? 4 : 2, yu, nx)[x] = o[2];
-    rowp(buf, plane, rb ? 6 : 8, rb ? y : yd, nx)[rb ? x : xr] = o[8];
-    rowp(buf, plane, r ? 3 : 1, y, nx)[xr] = o[1];
-    rowp(buf, plane, rt ? 7 : 5, rt ? y : yu, nx)[rt ? x : xr] = o[5] - df;
+    lid_push_scatter<T>(buf, plane, nx, x, y, l, r, t, b, o, df_lid, 0u, nx - 1);
 }
 
 // One node of the lid-driven cavity in pull form: the store map of pull-push.cpp:520-528 read from
@@ -444,9 +489,15 @@ __device__ __forceinline__ void lid_pull_node(const T *__restrict__ f, T *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// LID-DRIVEN sweeps, vector form.  Lanes whose 16 bytes touch x=0 or x=nx-1, and the rows that
-// touch the bottom wall or the lid, run the single-node form; every other lane runs the same
-// shifted-vector code as the periodic sweeps (no wrap can occur there).
+// LID-DRIVEN sweeps, vector form.  Rows that touch the bottom wall or the lid, and the two lanes
+// of a row whose 16 bytes touch a side wall, stream node by node with the reference's target map;
+// every other lane runs the periodic sweeps' vector code (no wrap can occur there).
+//
+// PULL: shifted vector loads, aligned stores (as k_pull_periodic_vec).
+// PUSH: aligned loads and whole aligned stores built with wavefront shuffles and one halo node at
+// each end of the wave's chunk (as k_push_periodic_vec).  Every lane writes exactly the x range it
+// owns: the wall lanes' node-wise scatter skips the one target that belongs to the neighbouring
+// lane's vector and adds the one element per channel that arrives from that neighbour.
 template <typename T, int V, int BLOCK, bool PULL>
 __global__ void __launch_bounds__(BLOCK)
 k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
@@ -456,36 +507,29 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
     const uint32_t x0 = (chunk * BLOCK + threadIdx.x) * V;
     if (x0 >= g.nx || y >= g.y_hi) return;
     const size_t plane = (size_t)g.ny * g.nx;
-    {
-        const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
-        const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
-        const bool edge_lane = (x0 == 0) || (x0 + V == g.nx);
-        if (t || b || edge_lane) {
+    const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
+    const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
+    const bool wall_lane = (x0 == 0) || (x0 + V == g.nx);
+    if (PULL) {
+        if (t || b || wall_lane) {
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const uint32_t x = x0 + i;
-                const bool l = (x == 0), r = (x == g.nx - 1);
-                if (PULL) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
-                else      lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+                lid_pull_node<T>(f, buf, plane, g.nx, x, y, x == 0, x == g.nx - 1, t, b, om, df_lid);
             }
             return;
         }
         const uint32_t yu = y + 1, yd = y - 1;
         T c[9][V];
-        if (PULL) {
-            load_u<T, V>(c[7], rowp(f, plane, 7, yu, g.nx) + (x0 + 1));
-            load_a<T, V>(c[4], rowp(f, plane, 4, yu, g.nx) + x0);
-            load_u<T, V>(c[8], rowp(f, plane, 8, yu, g.nx) + (x0 - 1));
-            load_u<T, V>(c[3], rowp(f, plane, 3, y, g.nx) + (x0 + 1));
-            load_a<T, V>(c[0], rowp(f, plane, 0, y, g.nx) + x0);
-            load_u<T, V>(c[1], rowp(f, plane, 1, y, g.nx) + (x0 - 1));
-            load_u<T, V>(c[6], rowp(f, plane, 6, yd, g.nx) + (x0 + 1));
-            load_a<T, V>(c[2], rowp(f, plane, 2, yd, g.nx) + x0);
-            load_u<T, V>(c[5], rowp(f, plane, 5, yd, g.nx) + (x0 - 1));
-        } else {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
-        }
+        load_u<T, V>(c[7], rowp(f, plane, 7, yu, g.nx) + (x0 + 1));
+        load_a<T, V>(c[4], rowp(f, plane, 4, yu, g.nx) + x0);
+        load_u<T, V>(c[8], rowp(f, plane, 8, yu, g.nx) + (x0 - 1));
+        load_u<T, V>(c[3], rowp(f, plane, 3, y, g.nx) + (x0 + 1));
+        load_a<T, V>(c[0], rowp(f, plane, 0, y, g.nx) + x0);
+        load_u<T, V>(c[1], rowp(f, plane, 1, y, g.nx) + (x0 - 1));
+        load_u<T, V>(c[6], rowp(f, plane, 6, yd, g.nx) + (x0 + 1));
+        load_a<T, V>(c[2], rowp(f, plane, 2, yd, g.nx) + x0);
+        load_u<T, V>(c[5], rowp(f, plane, 5, yd, g.nx) + (x0 - 1));
         T o[9][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -495,21 +539,101 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 #pragma unroll
             for (int q = 0; q < 9; ++q) o[q][i] = r[q];
         }
-        if (PULL) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
-        } else {
-            store_u<T, V>(rowp(buf, plane, 7, yd, g.nx) + (x0 - 1), o[7]);
-            store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
-            store_u<T, V>(rowp(buf, plane, 8, yd, g.nx) + (x0 + 1), o[8]);
-            store_u<T, V>(rowp(buf, plane, 3, y, g.nx) + (x0 - 1), o[3]);
-            store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
-            store_u<T, V>(rowp(buf, plane, 1, y, g.nx) + (x0 + 1), o[1]);
-            store_u<T, V>(rowp(buf, plane, 6, yu, g.nx) + (x0 - 1), o[6]);
-            store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
-            store_u<T, V>(rowp(buf, plane, 5, yu, g.nx) + (x0 + 1), o[5]);
-        }
+        for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
+        return;
     }
+
+    // ---- push ----
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const bool first = (lane == 0) && (x0 != 0);                       // needs the node left of the chunk
+    const bool last = (lane == kWave - 1) && (x0 + V != g.nx);         // needs the node right of it
+    const T *rq[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) rq[q] = rowp(f, plane, q, y, g.nx);
+    T c[9][V];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rq[q] + x0);
+    T h[9], ho[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { h[q] = T(0); ho[q] = T(0); }
+    if (first || last) {
+        const uint32_t hx = first ? x0 - 1 : x0 + V;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) h[q] = rq[q][hx];
+    }
+    T o[9][V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        T r[9];
+        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+                   c[8][i], om, r);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+    }
+    if (first || last) collide<T>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
+    // shuffles are executed by every lane of the wave, wall lanes included (their neighbours read
+    // from them)
+    T d[6][V];
+    const int qs_left[3] = {8, 1, 5};    // +x movers: first element comes from the left
+    const int qs_right[3] = {7, 3, 6};   // -x movers: last element comes from the right
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = qs_left[k];
+        const T nb = __shfl_up(o[q][V - 1], 1, kWave);
+        d[k][0] = first ? ho[q] : nb;
+#pragma unroll
+        for (int i = 1; i < V; ++i) d[k][i] = o[q][i - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = qs_right[k];
+        const T nb = __shfl_down(o[q][0], 1, kWave);
+        d[3 + k][V - 1] = last ? ho[q] : nb;
+#pragma unroll
+        for (int i = 0; i < V - 1; ++i) d[3 + k][i] = o[q][i + 1];
+    }
+    if (t || b || wall_lane) {
+        // node-wise streaming with the wall map.  In wall rows every lane does this, so all targets
+        // are written; in other rows only the side-wall lanes do, and the target that crosses into
+        // the neighbouring lane's vector is left to that lane.
+        const bool whole_row = t || b;
+        const uint32_t x_min = whole_row ? 0u : x0, x_max = whole_row ? g.nx - 1 : x0 + V - 1;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const uint32_t x = x0 + i;
+            T oi[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) oi[q] = o[q][i];
+            lid_push_scatter<T>(buf, plane, g.nx, x, y, x == 0, x == g.nx - 1, t, b, oi, df_lid, x_min, x_max);
+        }
+        if (!whole_row) {
+            // ... and the one element per x-moving channel that arrives in this lane's range from
+            // the neighbouring lane's nodes
+            const uint32_t yu = y + 1, yd = y - 1;
+            if (x0 != 0) {            // right-wall lane: +x movers from the lane to the left
+                rowp(buf, plane, 8, yd, g.nx)[x0] = d[0][0];
+                rowp(buf, plane, 1, y, g.nx)[x0] = d[1][0];
+                rowp(buf, plane, 5, yu, g.nx)[x0] = d[2][0];
+            }
+            if (x0 + V != g.nx) {     // left-wall lane: -x movers from the lane to the right
+                rowp(buf, plane, 7, yd, g.nx)[x0 + V - 1] = d[3][V - 1];
+                rowp(buf, plane, 3, y, g.nx)[x0 + V - 1] = d[4][V - 1];
+                rowp(buf, plane, 6, yu, g.nx)[x0 + V - 1] = d[5][V - 1];
+            }
+        }
+        return;
+    }
+    const uint32_t yu = y + 1, yd = y - 1;
+    store_a<T, V>(rowp(buf, plane, 7, yd, g.nx) + x0, d[3]);
+    store_a<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
+    store_a<T, V>(rowp(buf, plane, 8, yd, g.nx) + x0, d[0]);
+    store_a<T, V>(rowp(buf, plane, 3, y, g.nx) + x0, d[4]);
+    store_a<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
+    store_a<T, V>(rowp(buf, plane, 1, y, g.nx) + x0, d[1]);
+    store_a<T, V>(rowp(buf, plane, 6, yu, g.nx) + x0, d[5]);
+    store_a<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
+    store_a<T, V>(rowp(buf, plane, 5, yu, g.nx) + x0, d[2]);
 }
 
 // ------------------------------------------------------------------------------------------
