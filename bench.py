@@ -121,11 +121,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LBM_BENCH_REHEARSE=1: rehearsal of the multi-rank code path on a box with fewer GPUs than
+    # ranks (all ranks share the visible GPUs, transport gloo); never a measurement
+    rehearse = os.environ.get("LBM_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from lbm_amd import Simulation, SlabSimulation, capi
     if args.threads_x or args.waves_per_cu:
@@ -192,7 +199,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL over gloo on shared GPUs: not a measurement)",
             "config": {
                 "workload": workload,
                 "scene": args.scene, "scheme": args.scheme, "nx": nx, "ny_global": ny_glob,

@@ -511,7 +511,7 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
     const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
     const bool wall_lane = (x0 == 0) || (x0 + V == g.nx);
     if (PULL) {
-        if (t || b || wall_lane) {
+        if (t || b) {
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const uint32_t x = x0 + i;
@@ -519,17 +519,37 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
             }
             return;
         }
+        // rows away from the bottom wall and the lid: the periodic pull code; the shifted loads of
+        // the two side-wall lanes reach one element outside the row (still inside the array, see
+        // k_pull_periodic_vec) and that element is replaced by the node's own opposite population
+        // (half-way bounce-back; the lid term is zero in these rows but is added as the reference
+        // adds it, pull-push.cpp:522,528)
         const uint32_t yu = y + 1, yd = y - 1;
+        const T *r7 = rowp(f, plane, 7, yu, g.nx), *r4 = rowp(f, plane, 4, yu, g.nx), *r8 = rowp(f, plane, 8, yu, g.nx);
+        const T *r3 = rowp(f, plane, 3, y, g.nx), *r0 = rowp(f, plane, 0, y, g.nx), *r1 = rowp(f, plane, 1, y, g.nx);
+        const T *r6 = rowp(f, plane, 6, yd, g.nx), *r2 = rowp(f, plane, 2, yd, g.nx), *r5 = rowp(f, plane, 5, yd, g.nx);
+        const ptrdiff_t xl = (ptrdiff_t)x0 - 1, xr = (ptrdiff_t)x0 + 1;
         T c[9][V];
-        load_u<T, V>(c[7], rowp(f, plane, 7, yu, g.nx) + (x0 + 1));
-        load_a<T, V>(c[4], rowp(f, plane, 4, yu, g.nx) + x0);
-        load_u<T, V>(c[8], rowp(f, plane, 8, yu, g.nx) + (x0 - 1));
-        load_u<T, V>(c[3], rowp(f, plane, 3, y, g.nx) + (x0 + 1));
-        load_a<T, V>(c[0], rowp(f, plane, 0, y, g.nx) + x0);
-        load_u<T, V>(c[1], rowp(f, plane, 1, y, g.nx) + (x0 - 1));
-        load_u<T, V>(c[6], rowp(f, plane, 6, yd, g.nx) + (x0 + 1));
-        load_a<T, V>(c[2], rowp(f, plane, 2, yd, g.nx) + x0);
-        load_u<T, V>(c[5], rowp(f, plane, 5, yd, g.nx) + (x0 - 1));
+        load_u<T, V>(c[7], r7 + xr);
+        load_a<T, V>(c[4], r4 + x0);
+        load_u<T, V>(c[8], r8 + xl);
+        load_u<T, V>(c[3], r3 + xr);
+        load_a<T, V>(c[0], r0 + x0);
+        load_u<T, V>(c[1], r1 + xl);
+        load_u<T, V>(c[6], r6 + xr);
+        load_a<T, V>(c[2], r2 + x0);
+        load_u<T, V>(c[5], r5 + xl);
+        const T df0 = T(0.);
+        if (x0 == 0) {              // left wall: 1 <- 3, 5 <- 7, 8 <- 6 of the node itself
+            c[1][0] = rowp(f, plane, 3, y, g.nx)[0];
+            c[5][0] = rowp(f, plane, 7, y, g.nx)[0];
+            c[8][0] = rowp(f, plane, 6, y, g.nx)[0] + df0;
+        }
+        if (x0 + V == g.nx) {       // right wall: 3 <- 1, 6 <- 8, 7 <- 5
+            c[3][V - 1] = rowp(f, plane, 1, y, g.nx)[g.nx - 1];
+            c[6][V - 1] = rowp(f, plane, 8, y, g.nx)[g.nx - 1];
+            c[7][V - 1] = rowp(f, plane, 5, y, g.nx)[g.nx - 1] - df0;
+        }
         T o[9][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -623,6 +643,13 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
             }
         }
         return;
+    }
+    // the lid term is zero in these rows; it is still added as the reference adds it
+    // (pull-push.cpp:522,528), which only matters for the sign of an exact zero
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        d[5][i] = d[5][i] + T(0.);
+        d[2][i] = d[2][i] - T(0.);
     }
     const uint32_t yu = y + 1, yd = y - 1;
     store_a<T, V>(rowp(buf, plane, 7, yd, g.nx) + x0, d[3]);

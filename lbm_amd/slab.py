@@ -123,6 +123,11 @@ class SlabSimulation:
         self.t = 0
 
         self.cuda = self.device.type == "cuda"
+        # RCCL ("nccl") orders its transfers on the stream they are issued from.  Any other transport
+        # (gloo, used for rehearsals and tests) is driven by host threads that know nothing about
+        # streams, so device work must be drained by the host before every exchange.
+        self.stream_ordered = (self.world == 1 or not self.cuda
+                               or dist.get_backend(self.group) == "nccl")
         self.overlap = bool(overlap) and self.cuda
         if self.cuda:
             self.compute_stream = torch.cuda.current_stream(self.device)
@@ -201,6 +206,8 @@ class SlabSimulation:
                     for q in UP_CHANNELS:
                         p2p.append(dist.P2POp(dist.irecv, a[q, r_dn, xs(q)], self._peer(self.lower), self.group, tag=q))
                 if p2p:
+                    if not self.stream_ordered:
+                        (self.comm_stream if self.overlap else self.compute_stream).synchronize()
                     for req in dist.batch_isend_irecv(p2p):
                         req.wait()
             if self.cuda and self.overlap:
@@ -253,6 +260,8 @@ class SlabSimulation:
         self._join_halo()
         self.backend.max_velocity_dev(self._max, self.f, 1, self.n + 1)
         if self.world > 1:
+            if not self.stream_ordered:
+                torch.cuda.synchronize(self.device)
             dist.all_reduce(self._max[:1], op=dist.ReduceOp.MAX, group=self.group)
         return float(self._max[0].item())
 
@@ -266,6 +275,8 @@ class SlabSimulation:
         mine = self.interior().contiguous()
         if self.world == 1:
             return mine
+        if not self.stream_ordered:
+            torch.cuda.synchronize(self.device)
         if self.rank == 0:
             parts = [mine]
             for r in range(1, self.world):

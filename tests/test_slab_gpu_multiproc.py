@@ -47,6 +47,40 @@ def _worker(rank, world, store_path, out_path):
         dist.destroy_process_group()
 
 
+def _worker_big(rank, world, store_path, out_dir):
+    """Slabs large enough that the interior sweep really overlaps the exchange.  The shear wave is
+    x-invariant, so each rank checks its rows against an 8-column oracle run of the global lattice."""
+    sys.path.insert(0, ROOT)
+    from lbm_amd.slab import SlabSimulation
+    from oracle import oracle as orc
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
+    ok = True
+    try:
+        for scheme, overlap in (("pull", True), ("push", True), ("pull", False)):
+            nx, ny, steps, omega = 8192, 1024, 12, 0.5
+            sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=torch.float32, omega=omega,
+                                 device="cuda:0", overlap=overlap)
+            sim.step(steps)
+            vmax = sim.max_velocity()
+            want, _ = orc.run("shear", scheme, 8, ny, steps, omega, np.float32)
+            col = torch.from_numpy(np.ascontiguousarray(want[:, sim.y_below:sim.y_below + sim.n, :1])).cuda()
+            same = bool((sim.interior().view(torch.int32) == col.view(torch.int32)).all())
+            ok = ok and same and vmax == float(orc.max_velocity(want))
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_four_ranks_with_real_overlap_work():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_big, args=(4, os.path.join(tmp, "store"), tmp), nprocs=4, join=True)
+        for r in range(4):
+            assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"
+
+
 def test_two_ranks_on_one_gpu_reproduce_the_oracle():
     from oracle import oracle as orc
     with tempfile.TemporaryDirectory() as tmp:
