@@ -54,14 +54,16 @@ unsigned g_waves_per_cu = 0;
 constexpr unsigned kDefaultThreadsX = 64;
 constexpr unsigned kWavesPerCU_f32 = 6;       // top of the plateau for fp32 pull and push (4096^2 .. 32768x8192)
 constexpr unsigned kWavesPerCU_f64_pull = 5;  // fp64 pull: 4 is best by 1 % but sits on the cliff to 3
-constexpr unsigned kWavesPerCU_f64_push = 6;  // fp64 push (aligned-store form): 6 beats 5 by 4 %
+constexpr unsigned kWavesPerCU_f64_push = 6;
+constexpr unsigned kWavesPerCU_cache_resident = 16;  // fp64 push (aligned-store form): 6 beats 5 by 4 %
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr size_t kMaxDynamicLds = 64 * 1024;
 
 // Re-deal workgroups so that one XCD walks whole rows (lbm::block_coords).  Off by default:
 // measured on MI355X (16384^2) it removes the 8 % FETCH_SIZE excess of the plain mapping but lowers
 // the achieved rate (fp32 pull 6.1 -> 5.7 TB/s, fp64 pull 5.8 -> 5.6); the excess lines are cheap
-// (served on-die), the lost address-order locality is not.  LBM_XCD_ROWS=1 enables it.
+// (served on-die), the lost address-order locality is not.  A finer variant (one row at a time, each
+// XCD a contiguous eighth of the row) lost even more (6.16 -> 5.38 TB/s).  LBM_XCD_ROWS=1 enables it.
 int xcd_rows_default()
 {
     const char *e = getenv("LBM_XCD_ROWS");
@@ -129,9 +131,13 @@ dim3 sweep_grid(uint64_t lanes_per_row, unsigned block, uint64_t rows)
 }
 
 // Dynamic-LDS bytes per workgroup that leave room for `waves` resident waves per CU.
-size_t residency_ballast(unsigned block, size_t elem_size, bool pull)
+size_t residency_ballast(unsigned block, size_t elem_size, bool pull, uint64_t nx, uint64_t ny)
 {
+    // both arrays resident in the 256 MiB Infinity Cache: the L2 cliff does not bite and more waves
+    // hide more latency (1024^2 fp32: 66.3 GLUPS at 16-24 waves/CU against 64.5 at 6)
+    const bool cache_resident = 2ull * 9ull * nx * ny * elem_size <= (192ull << 20);
     const unsigned waves = g_waves_per_cu ? g_waves_per_cu
+                           : cache_resident ? kWavesPerCU_cache_resident
                            : (elem_size == 4 ? kWavesPerCU_f32 : (pull ? kWavesPerCU_f64_pull : kWavesPerCU_f64_push));
     const unsigned waves_per_block = block / 64;
     unsigned blocks_per_cu = waves / waves_per_block;
@@ -200,7 +206,7 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block, sizeof(T), PULL);
+        const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         LBM_FOR_BLOCK(block,
             if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
             else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
@@ -301,7 +307,7 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
-        const size_t lds = residency_ballast(block, sizeof(T), PULL);
+        const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {
