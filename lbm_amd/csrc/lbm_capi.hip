@@ -210,6 +210,15 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
         LBM_FOR_BLOCK(block,
             if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
             else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
+    } else if (nx >= 4 * V) {
+        // rows that are not a whole number of 16-byte vectors: element-aligned vector kernel
+        const uint64_t lanes = (nx + V - 1) / V;
+        const unsigned block = pick_block(lanes);
+        const dim3 grid = sweep_grid(lanes, block, rows);
+        const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
+        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B>), grid, dim3(B), lds, stream, f, buf, g, om, (T)0))
     } else {
         const unsigned block = pick_block(nx);
         const dim3 grid = sweep_grid(nx, block, rows);
@@ -310,6 +319,14 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
         const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
+    } else if (nx >= 4 * V) {
+        const uint64_t lanes = (nx + V - 1) / V;
+        const unsigned block = pick_block(lanes);
+        const dim3 grid = sweep_grid(lanes, block, rows);
+        const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
+        constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {
         const unsigned block = pick_block(nx);
         const dim3 grid = sweep_grid(nx, block, rows);

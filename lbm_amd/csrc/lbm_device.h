@@ -664,8 +664,94 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 }
 
 // ------------------------------------------------------------------------------------------
-// Scalar kernels: one node per lane over the rectangle [x_lo,x_hi) x [y_lo,y_hi).  Any nx.
+// Vector sweeps for rows that cannot be accessed with naturally aligned 16-byte vectors (NX not a
+// multiple of V, e.g. the 22627 x 22627 fp64 lattice of the reference's benchmark.py:12): every
+// access is an element-aligned 128-bit vector, shifted where the stencil asks for it.  The first
+// lane of a row, the partial last lane and (lid scenes) the wall rows stream node by node.
+// MODE as ScalarMode below.
 enum ScalarMode { kPullPeriodic = 0, kPushPeriodic = 1, kPullLid = 2, kPushLid = 3 };
+
+template <typename T, int V, int MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
+{
+    uint32_t chunk, y;
+    block_coords(g, chunk, y);
+    const uint32_t x0 = (chunk * BLOCK + threadIdx.x) * V;
+    if (x0 >= g.nx || y >= g.y_hi) return;
+    const size_t plane = (size_t)g.ny * g.nx;
+    constexpr bool LID = (MODE == kPullLid || MODE == kPushLid);
+    constexpr bool PULL = (MODE == kPullPeriodic || MODE == kPullLid);
+    const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
+    const bool t = LID && (yg == g.ny_glob - 1), b = LID && (yg == 0);
+    const uint32_t rem = g.nx - x0;
+    if (x0 == 0 || rem <= (uint32_t)V || t || b) {
+        // node by node, with the wrap (pull-push.cpp:255-258, :277-280) or the wall map
+        const uint32_t n = rem < (uint32_t)V ? rem : (uint32_t)V;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t x = x0 + i;
+            if (LID) {
+                const bool l = (x == 0), r = (x == g.nx - 1);
+                if (PULL) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+                else      lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+            } else {
+                const uint32_t xr = (x + 1 == g.nx) ? 0u : x + 1;
+                const uint32_t xl = (x == 0) ? g.nx - 1 : x - 1;
+                const uint32_t yu = row_up(g, y), yd = row_down(g, y);
+                if (PULL) pull_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+                else      push_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            }
+        }
+        return;
+    }
+    // here 0 < x0 and x0 + V < nx: no wrap, no wall inside the reach of this lane
+    const uint32_t yu = LID ? y + 1 : row_up(g, y), yd = LID ? y - 1 : row_down(g, y);
+    T c[9][V];
+    if (PULL) {
+        load_u<T, V>(c[7], rowp(f, plane, 7, yu, g.nx) + (x0 + 1));
+        load_u<T, V>(c[4], rowp(f, plane, 4, yu, g.nx) + x0);
+        load_u<T, V>(c[8], rowp(f, plane, 8, yu, g.nx) + (x0 - 1));
+        load_u<T, V>(c[3], rowp(f, plane, 3, y, g.nx) + (x0 + 1));
+        load_u<T, V>(c[0], rowp(f, plane, 0, y, g.nx) + x0);
+        load_u<T, V>(c[1], rowp(f, plane, 1, y, g.nx) + (x0 - 1));
+        load_u<T, V>(c[6], rowp(f, plane, 6, yd, g.nx) + (x0 + 1));
+        load_u<T, V>(c[2], rowp(f, plane, 2, yd, g.nx) + x0);
+        load_u<T, V>(c[5], rowp(f, plane, 5, yd, g.nx) + (x0 - 1));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) load_u<T, V>(c[q], rowp(f, plane, q, y, g.nx) + x0);
+    }
+    T o[9][V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        T r[9];
+        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+                   c[8][i], om, r);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+    }
+    if (PULL) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) store_u<T, V>(rowp(buf, plane, q, y, g.nx) + x0, o[q]);
+    } else {
+        if (LID) {  // zero lid term, added as the reference adds it (pull-push.cpp:522,528)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { o[6][i] = o[6][i] + T(0.); o[5][i] = o[5][i] - T(0.); }
+        }
+        store_u<T, V>(rowp(buf, plane, 7, yd, g.nx) + (x0 - 1), o[7]);
+        store_u<T, V>(rowp(buf, plane, 4, yd, g.nx) + x0, o[4]);
+        store_u<T, V>(rowp(buf, plane, 8, yd, g.nx) + (x0 + 1), o[8]);
+        store_u<T, V>(rowp(buf, plane, 3, y, g.nx) + (x0 - 1), o[3]);
+        store_u<T, V>(rowp(buf, plane, 0, y, g.nx) + x0, o[0]);
+        store_u<T, V>(rowp(buf, plane, 1, y, g.nx) + (x0 + 1), o[1]);
+        store_u<T, V>(rowp(buf, plane, 6, yu, g.nx) + (x0 - 1), o[6]);
+        store_u<T, V>(rowp(buf, plane, 2, yu, g.nx) + x0, o[2]);
+        store_u<T, V>(rowp(buf, plane, 5, yu, g.nx) + (x0 + 1), o[5]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Scalar kernels: one node per lane over the rectangle [x_lo,x_hi) x [y_lo,y_hi).  Any nx.
 
 template <typename T, int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)

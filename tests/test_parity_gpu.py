@@ -36,7 +36,10 @@ def gpu_sim(scene, scheme, nx, ny, dtype, omega):
     return Simulation(nx, ny, scene=scene, scheme=scheme, dtype=TORCH[dtype], omega=omega, device="cuda:0")
 
 
-SIZES = [(8, 6), (64, 48), (100, 60), (128, 96), (7, 5), (1030, 9), (2048, 4), (4, 3), (1, 1), (2, 7)]
+# (nx, ny): multiples of the vector width, odd / non-multiple row lengths (element-aligned vector
+# kernel), rows shorter than four vectors (one-node-per-lane kernel), degenerate lattices
+SIZES = [(8, 6), (64, 48), (100, 60), (128, 96), (7, 5), (1030, 9), (2048, 4), (4, 3), (1, 1), (2, 7),
+         (67, 12), (1027, 5), (262, 9), (17, 4), (513, 3)]
 CASES = [("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")]
 
 
@@ -72,7 +75,7 @@ def test_random_state_single_sweep(dtype):
     neighbour, which the x-invariant shear wave cannot."""
     from lbm_amd import ops
     rng = np.random.default_rng(1234)
-    for nx, ny in ((64, 33), (256, 17), (1024, 5), (37, 11), (4096, 3)):
+    for nx, ny in ((64, 33), (256, 17), (1024, 5), (37, 11), (4096, 3), (1029, 7), (130, 9), (22627, 3)):
         f = (1.0 / 9 + 0.02 * rng.standard_normal((9, ny, nx))).astype(dtype)
         d_f = torch.from_numpy(f).cuda()
         d_b = torch.full_like(d_f, float("nan"))
