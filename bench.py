@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=2048, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos on the compute stream")
+    ap.add_argument("--slab", action="store_true",
+                    help="N=1 only: run the y-slab code path with this GPU as its own periodic neighbour "
+                         "(halo rows through RCCL send/recv to self) to price the decomposition overhead")
     ap.add_argument("--threads-x", type=int, default=0, help="workgroup width hint (0 = built-in)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="resident-wave cap hint (0 = built-in)")
     return ap.parse_args()
@@ -143,7 +146,13 @@ def main():
     nx, ny_loc = args.nx, args.ny_per_gpu
     ny_glob = ny_loc * world
 
-    if world == 1:
+    if world == 1 and args.slab:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        sim = SlabSimulation(nx, ny_glob, scene=args.scene, scheme=args.scheme, dtype=dtype, omega=args.omega,
+                             device=device, overlap=not args.no_overlap, p2p_to_self=True)
+    elif world == 1:
         sim = Simulation(nx, ny_loc, scene=args.scene, scheme=args.scheme, dtype=dtype,
                          omega=args.omega, device=device)
     else:
@@ -204,7 +213,8 @@ def main():
                 "workload": workload,
                 "scene": args.scene, "scheme": args.scheme, "nx": nx, "ny_global": ny_glob,
                 "ny_per_gpu": ny_loc, "omega": args.omega,
-                "decomposition": "single device" if world == 1 else f"{world} y-slabs, 1 halo row, RCCL send/recv",
+                "decomposition": ("single device" if world == 1 and not args.slab else
+                                  f"{world} y-slab(s), 1 halo row, RCCL send/recv"),
                 "roofline_mlups_per_gpu": HBM_PEAK_GBS * 1e3 / bytes_per_node,
                 "frac_of_roofline_whole_job": mlups / (world * HBM_PEAK_GBS * 1e3 / bytes_per_node),
                 "max_velocity_after_run": vmax,
@@ -228,6 +238,7 @@ def main():
 
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -8,11 +8,13 @@ pair is already contiguous, so the three populations that cross a slab edge are 
 / received straight into the population array: no pack or unpack kernels (the reference needs six,
 main.cpp:238-273, :339-374).
 
-Per step (pull):  edge rows 1 and n of buf are computed first on the compute stream; a second
-stream then sends them to the neighbours' ghost rows (RCCL send/recv over xGMI when the backend
-is "nccl") while the compute stream updates the interior rows 2..n-1; the next step's edge rows
-wait for the exchange.  Push works the same way with the roles of ghost and edge rows swapped
-(values pushed into a ghost row belong to the neighbour's edge row).
+Per step, two streams run side by side.  The edge stream updates rows 1 and n and then exchanges
+halo rows with the neighbours (RCCL send/recv over xGMI when the backend is "nccl"); the interior
+stream updates rows 2..n-1.  The interior sweep of step t+1 needs only the interior and edge
+sweeps of step t, never the exchange, so it is never held up by communication; the edge sweeps of
+step t+1 follow the exchange of step t on their own stream.  Pull sends the freshly computed edge
+rows into the neighbours' ghost rows; push sends what was pushed into the ghost rows to the
+neighbours' edge rows.
 
 The multi-rank result is bit-identical to the single-device result: slabs are initialised from the
 global row index (the reference's own offset is wrong for ranks > 0, main.cpp:141-144, and is not
@@ -76,6 +78,24 @@ class HipBackend:
         self.ops.compute_velocities(vel, f, 0, y_lo, f.shape[2], y_hi)
 
 
+_EDGE_STREAMS = {}
+
+
+def _edge_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The one edge/communication stream of a device, shared by every slab on it.
+
+    Created once per process and device: which hardware queue a HIP stream lands on depends on how
+    many streams were created before it, and with RCCL's own streams in the same few queues a
+    process that kept taking fresh high-priority streams (one per slab object) was seen to stall on
+    its fourth.  Slabs that share the stream are simply ordered behind each other on it.
+    """
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _EDGE_STREAMS.get(key)
+    if s is None:
+        s = _EDGE_STREAMS[key] = torch.cuda.Stream(device, priority=-1)
+    return s
+
+
 class SlabSimulation:
     """One rank's slab of a global NX x NY lattice.
 
@@ -85,12 +105,17 @@ class SlabSimulation:
 
     def __init__(self, nx: int, ny_glob: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
                  dtype: torch.dtype = torch.float32, omega: float = 0.5, rho: float = 1.0,
-                 u: float = 0.1, device="cuda:0", backend=None, group=None, overlap: bool = True):
+                 u: float = 0.1, device="cuda:0", backend=None, group=None, overlap: bool = True,
+                 p2p_to_self: bool = False):
         if scene not in (SHEAR_WAVE, LID_DRIVEN):
             raise ValueError(f"unknown scene {scene!r}")
         if scheme not in ("pull", "push"):
             raise ValueError(f"unknown scheme {scheme!r}")
         self.group = group
+        # p2p_to_self: with a single rank, still route the periodic halo rows through the process
+        # group's send/recv (to this rank itself) instead of local copies -- exercises the real
+        # transport, e.g. RCCL on a one-GPU machine
+        self.p2p_to_self = bool(p2p_to_self)
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
@@ -126,14 +151,23 @@ class SlabSimulation:
         # RCCL ("nccl") orders its transfers on the stream they are issued from.  Any other transport
         # (gloo, used for rehearsals and tests) is driven by host threads that know nothing about
         # streams, so device work must be drained by the host before every exchange.
-        self.stream_ordered = (self.world == 1 or not self.cuda
-                               or dist.get_backend(self.group) == "nccl")
+        have_group = dist.is_available() and dist.is_initialized()
+        if self.p2p_to_self and not have_group:
+            raise RuntimeError("p2p_to_self needs an initialised process group")
+        self.stream_ordered = (not have_group or not self.cuda or dist.get_backend(self.group) == "nccl")
         self.overlap = bool(overlap) and self.cuda
         if self.cuda:
-            self.compute_stream = torch.cuda.current_stream(self.device)
-            self.comm_stream = torch.cuda.Stream(self.device) if self.overlap else self.compute_stream
-            self._edges_done = torch.cuda.Event()
-            self._halo_done = torch.cuda.Event()
+            self.compute_stream = torch.cuda.current_stream(self.device)   # interior sweeps
+            # High priority: the edge sweeps and the exchange are short and everybody waits for them.
+            # It also keeps this stream off the hardware queue of the interior stream (HIP gives
+            # priority levels their own queues); two streams multiplexed on one hardware queue are
+            # processed in submission order and the interior sweep would queue behind the exchange.
+            self.comm_stream = _edge_stream(self.device) if self.overlap else self.compute_stream
+            # per step parity (two of each, so that "the previous step's" event can still be waited
+            # for after this step's work has been submitted):
+            self._edges_done = [torch.cuda.Event(), torch.cuda.Event()]      # edge rows are in buf
+            self._interior_done = [torch.cuda.Event(), torch.cuda.Event()]   # interior rows are in buf
+            self._halo_done = torch.cuda.Event()       # the last exchange has completed
         self._halo_pending = False
 
         if scene == LID_DRIVEN:
@@ -142,12 +176,16 @@ class SlabSimulation:
             backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob)
         if self.scheme == "pull":
             # pull reads ghost rows of f: fill them from the neighbours' initial edge rows
+            if self.overlap:
+                self._interior_done[1].record(self.compute_stream)   # initialisation finished
+                self.comm_stream.wait_event(self._interior_done[1])
             self._exchange(self.f, pull=True)
             self._join_halo()
 
     # ------------------------------------------------------------------ exchange -------------
     def _exchange(self, a: torch.Tensor, pull: bool) -> None:
-        """Halo-row exchange on array `a` (runs on the communication stream).
+        """Halo-row exchange on array `a`, issued on the edge/communication stream; the caller has
+        ordered that stream after whatever produced the rows to be sent.
 
         pull: my edge rows -> the neighbours' ghost rows.   send a[DOWN,1] down, a[UP,n] up;
               receive a[UP,0] from below, a[DOWN,n+1] from above.
@@ -173,15 +211,9 @@ class SlabSimulation:
             if q in (5, 8):   # cx = +1
                 return slice(1, self.nx)
             return slice(None)
-        if self.cuda:
-            if self.overlap:
-                self._edges_done.record(self.compute_stream)
-                self.comm_stream.wait_event(self._edges_done)
-            ctx = torch.cuda.stream(self.comm_stream)
-        else:
-            ctx = _NullCtx()
+        ctx = torch.cuda.stream(self.comm_stream) if self.cuda else _NullCtx()
         with ctx:
-            if self.world == 1:
+            if self.world == 1 and not self.p2p_to_self:
                 if self.lower is not None:  # periodic: the neighbour is this rank itself
                     for q in DOWN_CHANNELS:
                         a[q, r_up, xs(q)].copy_(a[q, s_dn, xs(q)])
@@ -240,17 +272,32 @@ class SlabSimulation:
         n = self.n
         pull = self.scheme == "pull"
         for _ in range(nsteps):
-            # edge rows first (they are what the neighbours wait for) ...
-            self._join_halo()
-            self._sweep(1, 2)
-            if n >= 2:
-                self._sweep(n, n + 1)
-            # ... exchange them on the second stream while the interior rows are updated
-            self._exchange(self.buf, pull=pull)
-            self._sweep(2, n)
-            if not pull:
-                # pushed values received from the neighbours land in rows the next step reads
-                self._join_halo()
+            if self.overlap:
+                k = self.t & 1
+                p = k ^ 1
+                # edge stream: needs the previous step's interior rows (and, by stream order, its
+                # edge rows and exchange)
+                self.comm_stream.wait_event(self._interior_done[p])
+                # interior stream: needs the previous step's edge rows (and, by stream order, its
+                # interior rows); it never waits for an exchange
+                self.compute_stream.wait_event(self._edges_done[p])
+                # The interior sweep is submitted first: streams share a few hardware queues that
+                # are processed in submission order, and nothing of this step's edge/exchange work
+                # may sit in front of the big kernel.
+                self._sweep(2, n)
+                self._interior_done[k].record(self.compute_stream)
+                with torch.cuda.stream(self.comm_stream):
+                    self._sweep(1, 2)
+                    if n >= 2:
+                        self._sweep(n, n + 1)
+                    self._edges_done[k].record(self.comm_stream)
+                self._exchange(self.buf, pull=pull)
+            else:
+                self._sweep(1, 2)
+                if n >= 2:
+                    self._sweep(n, n + 1)
+                self._exchange(self.buf, pull=pull)
+                self._sweep(2, n)
             self.f, self.buf = self.buf, self.f
             self.t += 1
 

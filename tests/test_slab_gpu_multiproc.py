@@ -81,6 +81,49 @@ def test_four_ranks_with_real_overlap_work():
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"
 
 
+def _worker_rccl_self(rank, world, port, out_dir):
+    """World of one over RCCL: the periodic neighbours are this rank itself, and the halo rows go
+    through exactly the grouped send/recv on the second stream that a multi-GPU run uses."""
+    sys.path.insert(0, ROOT)
+    from lbm_amd.slab import SlabSimulation
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ok = True
+    try:
+        for scheme, tdt, ndt, nx, ny in (("pull", torch.float32, np.float32, 8192, 512),
+                                         ("push", torch.float32, np.float32, 8192, 512),
+                                         ("pull", torch.float64, np.float64, 4096, 256),
+                                         ("push", torch.float64, np.float64, 1030, 64)):
+            steps, omega = 15, 0.7
+            sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=tdt, omega=omega, device="cuda:0",
+                                 p2p_to_self=True)
+            assert sim.stream_ordered and sim.overlap
+            sim.step(steps)
+            vmax = sim.max_velocity()
+            want, _ = orc.run("shear", scheme, 8 if nx % 8 == 0 else nx, ny, steps, omega, ndt)
+            got = sim.interior()
+            if want.shape[2] == nx:
+                same = np.array_equal(got.cpu().numpy().view(np.uint8), want.view(np.uint8))
+            else:
+                col = torch.from_numpy(np.ascontiguousarray(want[:, :, :1])).cuda()
+                bits = torch.int32 if tdt == torch.float32 else torch.int64
+                same = bool((got.view(bits) == col.view(bits)).all())
+            ok = ok and same and vmax == float(orc.max_velocity(want))
+        with open(os.path.join(out_dir, "result.txt"), "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_with_self_as_both_neighbours():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_rccl_self, args=(1, 29541, tmp), nprocs=1, join=True)
+        assert open(os.path.join(tmp, "result.txt")).read() == "ok"
+
+
 def test_two_ranks_on_one_gpu_reproduce_the_oracle():
     from oracle import oracle as orc
     with tempfile.TemporaryDirectory() as tmp:
