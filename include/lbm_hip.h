@@ -119,6 +119,39 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
                       double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
                       uint64_t ny_glob, void *stream);
 
+/* ------------------------------------------------ several time steps per call ------------ */
+
+/* Each of the following replaces `nsteps` consecutive iterations of the reference's time loop
+ * (main.cpp:64-83 single rank: sweep, swap, sweep, ...; main.cpp:217-396 with halos) for rows
+ * [y_lo, y_hi): it reads f at time t and leaves time t + nsteps in buf, bit-identical to nsteps calls
+ * of the one-step entry point with the buffers swapped in between, while every population crosses
+ * HBM once.  nsteps = 1 .. lbm_fused_max_steps(); 1 forwards to the one-step entry point.
+ *
+ * Rows that the dependency cone of the updated rows reaches must be present in the array: with
+ * wrap_y = 0 the periodic forms read rows [y_lo - nsteps, y_hi + nsteps) (deep ghost rows: copies of
+ * the neighbouring slab's rows at time t), the lid forms the same range clipped at the walls.
+ * Returns LBM_ERR_UNSUPPORTED (nothing launched) when rows are not a whole number of 16-byte
+ * vectors; callers then take nsteps one-step sweeps. */
+
+/* Largest nsteps the fused entry points accept for this precision and row length (1 = unsupported). */
+int lbm_fused_max_steps(int prec, uint64_t nx);
+
+/* nsteps x pull_periodic (pull-push.cpp:5-73, :268-288). */
+int lbm_pull_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t y_lo, uint64_t y_hi, int wrap_y, int nsteps, void *stream);
+/* nsteps x push_periodic (pull-push.cpp:124-186, :246-266). */
+int lbm_push_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t y_lo, uint64_t y_hi, int wrap_y, int nsteps, void *stream);
+/* nsteps x push_lid_driven (pull-push.cpp:436-528, :290-309); row offset and cavity height as in
+ * lbm_push_lid_rows. */
+int lbm_push_lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                       double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                       uint64_t ny_glob, int nsteps, void *stream);
+/* nsteps x the pull form of the lid-driven cavity (lbm_pull_lid_rows). */
+int lbm_pull_lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                       double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                       uint64_t ny_glob, int nsteps, void *stream);
+
 /* ---------------------------------------------------------------- output path -------------- */
 
 /* Replaces compute_velocities (io.cpp:136-174).  vel is a device array [2][y_hi-y_lo][nx] (ux plane,

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "lbm_device.h"
+#include "lbm_fused.h"
 
 #pragma clang fp contract(off)
 
@@ -364,6 +365,120 @@ int lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doubl
                : sweep_lid_rows<double, PULL>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, st);
 }
 
+// ---- several time steps per pass (lbm_fused.h) ------------------------------------------------
+// Rows stored per wavefront.  Measured on MI355X: long segments amortise the K-1 (pull) or K (push)
+// rows of redundant work at either end, short ones keep more wavefronts in flight; at 16384^2 fp32
+// the best are 16 rows for K=2 (147 GLUPS), 32 for K=3 (193), 64 for K=4 (217), and a 4096^2 lattice
+// wants 16 rows even for K=4 (168 GLUPS against 132 with 64): keep at least ~4 waves per SIMD lane
+// group of the chip in the grid before growing the segment.
+unsigned fused_seg_rows_default()
+{
+    const char *e = getenv("LBM_FUSED_SEG_ROWS");
+    return e ? (unsigned)atoi(e) : 0u;
+}
+unsigned g_fused_seg_rows = fused_seg_rows_default();
+
+template <typename T>
+bool fused_supported(uint64_t nx)
+{
+    constexpr int V = vec_width<T>();
+    return nx % V == 0 && nx >= 2 * V;
+}
+
+template <typename T, bool PUSH, bool LID>
+int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_, double u_,
+                uint64_t y_lo, uint64_t y_hi, int wrap_y, int64_t y_goff, uint64_t ny_glob, int k,
+                hipStream_t stream)
+{
+    if (y_lo == y_hi) return LBM_OK;
+    constexpr int V = vec_width<T>();
+    constexpr uint64_t W = lbm::kWave - 2 * lbm::kFusedHalo;
+    const T *f = (const T *)f_;
+    T *buf = (T *)buf_;
+    const T om = (T)om_;
+    const T rho = (T)rho_, u = (T)u_;
+    const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
+    const uint64_t rows = y_hi - y_lo;
+    const uint64_t nstrips = (nx / V + W - 1) / W;
+    uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k == 2 ? 16 : k == 3 ? 32 : 64);
+    if (!g_fused_seg_rows)
+        while (seg > 8 && nstrips * ((rows + seg - 1) / seg) < 4096) seg /= 2;
+    if (seg > rows) seg = rows;
+    const uint64_t nsegs = (rows + seg - 1) / seg;
+    if (nstrips * nsegs > 0x7fffffffull)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "lattice too large for one fused launch");
+    lbm::FusedGeom g;
+    g.nx = (uint32_t)nx; g.ny = (uint32_t)ny; g.y_lo = (uint32_t)y_lo; g.y_hi = (uint32_t)y_hi;
+    g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
+    g.y_goff = y_goff; g.ny_glob = ny_glob;
+    const dim3 grid((unsigned)(nstrips * nsegs)), block(lbm::kWave);
+    switch (k) {
+        case 2: hipLaunchKernelGGL((lbm::k_fused<T, V, 2, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
+        case 3: hipLaunchKernelGGL((lbm::k_fused<T, V, 3, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
+        case 4: hipLaunchKernelGGL((lbm::k_fused<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
+        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 2..%d", k, lbm::kFusedMaxSteps);
+    }
+    return launch_status("fused sweep");
+}
+
+template <bool PULL>
+int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                   uint64_t y_lo, uint64_t y_hi, int wrap_y, int k, void *stream)
+{
+    if (k < 1 || k > lbm::kFusedMaxSteps)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+    if (k == 1) return periodic_rows<PULL>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (!wrap_y && y_lo < y_hi && (y_lo < (uint64_t)k || y_hi + (uint64_t)k > ny))
+        return fail(LBM_ERR_INVALID_ARGUMENT,
+                    "%d fused steps of rows [%llu,%llu) need %d ghost rows on either side inside [0,%llu)",
+                    k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
+    if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 16-byte vectors (nx=%llu)",
+                    (unsigned long long)nx);
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32
+               ? sweep_fused<float, !PULL, false>(f, buf, nx, ny, om, 0., 0., y_lo, y_hi, wrap_y, 0, 0, k, st)
+               : sweep_fused<double, !PULL, false>(f, buf, nx, ny, om, 0., 0., y_lo, y_hi, wrap_y, 0, 0, k, st);
+}
+
+template <bool PULL>
+int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, double rho_eq,
+              double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff, uint64_t ny_glob, int k,
+              void *stream)
+{
+    if (k < 1 || k > lbm::kFusedMaxSteps)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+    if (k == 1) return lid_rows<PULL>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
+    if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (y_lo < y_hi) {
+        const int64_t g_lo = (int64_t)y_lo + y_goff, g_hi = (int64_t)y_hi + y_goff;
+        if (ny_glob == 0 || ny_glob > kMaxExtent || g_lo < 0 || (uint64_t)g_hi > ny_glob)
+            return fail(LBM_ERR_INVALID_ARGUMENT,
+                        "rows [%llu,%llu) + offset %lld leave the cavity of height %llu",
+                        (unsigned long long)y_lo, (unsigned long long)y_hi, (long long)y_goff,
+                        (unsigned long long)ny_glob);
+        // rows of the cavity within k rows of the range must be present in the array
+        const uint64_t need_lo = (uint64_t)g_lo < (uint64_t)k ? (uint64_t)g_lo : (uint64_t)k;
+        const uint64_t above = ny_glob - (uint64_t)g_hi;
+        const uint64_t need_hi = above < (uint64_t)k ? above : (uint64_t)k;
+        if (y_lo < need_lo || ny - y_hi < need_hi)
+            return fail(LBM_ERR_INVALID_ARGUMENT,
+                        "%d fused steps of rows [%llu,%llu) need %llu ghost rows below and %llu above inside the array",
+                        k, (unsigned long long)y_lo, (unsigned long long)y_hi,
+                        (unsigned long long)need_lo, (unsigned long long)need_hi);
+    }
+    if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 16-byte vectors (nx=%llu)",
+                    (unsigned long long)nx);
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32
+               ? sweep_fused<float, !PULL, true>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, k, st)
+               : sweep_fused<double, !PULL, true>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, k, st);
+}
+
 // ---- initialisation --------------------------------------------------------------------
 // f_eq of init.cpp:57-84, evaluated on the host.  The bracket is double even for T=float because
 // the reference writes 9./2. and 3./2. (init.cpp:81-82); 1+3*cu, cu*cu and u_2 are formed in T.
@@ -610,6 +725,35 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
                       uint64_t ny_glob, void *stream)
 {
     return lid_rows<true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
+}
+
+int lbm_fused_max_steps(int prec, uint64_t nx)
+{
+    if (prec != LBM_F32 && prec != LBM_F64) return 0;
+    const bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
+    return ok ? lbm::kFusedMaxSteps : 1;
+}
+int lbm_pull_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t y_lo, uint64_t y_hi, int wrap_y, int nsteps, void *stream)
+{
+    return periodic_fused<true>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, nsteps, stream);
+}
+int lbm_push_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                            uint64_t y_lo, uint64_t y_hi, int wrap_y, int nsteps, void *stream)
+{
+    return periodic_fused<false>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, nsteps, stream);
+}
+int lbm_push_lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                       double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                       uint64_t ny_glob, int nsteps, void *stream)
+{
+    return lid_fused<false>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, nsteps, stream);
+}
+int lbm_pull_lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
+                       double rho_eq, double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff,
+                       uint64_t ny_glob, int nsteps, void *stream)
+{
+    return lid_fused<true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, nsteps, stream);
 }
 
 int lbm_compute_velocities(const void *f, void *vel, int prec, uint64_t nx, uint64_t ny,

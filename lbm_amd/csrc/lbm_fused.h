@@ -1,0 +1,355 @@
+// Several time steps per pass over memory (temporal blocking) for the D2Q9 BGK sweeps on gfx950.
+//
+// A single collide-and-stream step moves 18 populations per node through HBM for ~110 flops: the
+// one-step sweeps of lbm_device.h sit at the memory roofline with the vector ALUs 80 % idle.  These
+// kernels advance K = 2..4 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
+// ...) while reading every population once and writing it once:
+//
+//   * one wavefront owns a strip of 64 x 16 bytes of a row and marches it through a segment of
+//     rows; one row of 9 x 1 KiB is loaded per iteration (prefetched one iteration ahead);
+//   * the time levels between the loaded and the stored one never leave the register file: per
+//     level a ring of nine vectors holds the populations that the next rows still need ((2,5,6) of
+//     two rows, (0,1,3) of one row), so iteration i relaxes row R at level 1, row R-1 at level 2,
+//     ... and stores row R-K+1 at level K;
+//   * the x neighbours that the streaming step needs come from the adjacent lanes through DPP
+//     wavefront shifts -- no LDS, no barriers, every global access a naturally aligned 16 bytes;
+//   * the dependency cone is paid for with redundant work at the strip and segment edges: two
+//     vectors (32 bytes) of x halo per side, so that the 60 stored vectors of a strip cover whole
+//     64-byte lines (partially written lines cost 20 % of the achieved HBM rate), and K or K-1 rows
+//     of y halo per segment end;
+//   * arithmetic per node and time step is the one-step kernels' `collide`, in the same order, so
+//     the result is bit-identical to K one-step sweeps.
+//
+// Pull scheme (stored state: post-collision populations):  [gather from memory, relax] then K-1 x
+// [gather from registers, relax], store.   Push scheme (stored state: post-streaming populations):
+// [relax the loaded row] then K-1 x [gather, relax], one more gather, store.
+//
+// Lid-driven cavity: the gathers apply the half-way bounce-back map of pull-push.cpp:496-528 read
+// from the destination side (as lid_pull_node / lid_push_scatter do for one step): a population
+// whose upstream node lies behind a wall is the destination node's own opposite population, the
+// two that bounce off the lid carry -+ rho_eq*u_lid/6.
+#pragma once
+#include "lbm_device.h"
+
+#pragma clang fp contract(off)
+
+namespace lbm {
+
+constexpr int kFusedHalo = 2;      // vectors of x halo on either side of a strip
+constexpr int kFusedMaxSteps = 4;  // K*1 node of halo per step must fit in kFusedHalo vectors (fp64: 4 nodes)
+
+struct FusedGeom {
+    uint32_t nx, ny;        // row length, rows in the array
+    uint32_t y_lo, y_hi;    // rows to advance
+    int wrap_y;             // rows outside [0,ny) wrap around (whole periodic lattice on this device)
+    uint32_t seg_rows;      // rows stored per wavefront
+    uint32_t nstrips, nsegs;
+    int64_t y_goff;         // lid scenes: global row = row + y_goff
+    uint64_t ny_glob;       //             cavity height
+};
+
+// Value held by the lane below / above in the wavefront (DPP wave_shr:1 / wave_shl:1).  Lane 0 /
+// lane 63 keep their own value; they are halo lanes whose result is never stored.
+template <typename T>
+__device__ __forceinline__ T from_lane_below(T v)
+{
+    constexpr int N = sizeof(T) / 4;
+    union { T t; int w[N]; } a, b;
+    a.t = v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(a.w[k], a.w[k], 0x138, 0xf, 0xf, false);
+    return b.t;
+}
+template <typename T>
+__device__ __forceinline__ T from_lane_above(T v)
+{
+    constexpr int N = sizeof(T) / 4;
+    union { T t; int w[N]; } a, b;
+    a.t = v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(a.w[k], a.w[k], 0x130, 0xf, 0xf, false);
+    return b.t;
+}
+
+// d[i] = value at x-1 of a row held as one vector per lane / value at x+1
+template <typename T, int V>
+__device__ __forceinline__ void arrive_from_left(T (&d)[V], const T (&s)[V])
+{
+    d[0] = from_lane_below(s[V - 1]);
+#pragma unroll
+    for (int i = 1; i < V; ++i) d[i] = s[i - 1];
+}
+template <typename T, int V>
+__device__ __forceinline__ void arrive_from_right(T (&d)[V], const T (&s)[V])
+{
+    d[V - 1] = from_lane_above(s[0]);
+#pragma unroll
+    for (int i = 0; i < V - 1; ++i) d[i] = s[i + 1];
+}
+
+// What a lane knows about walls (lid scenes only; all false otherwise).
+struct WallFlags {
+    bool t, b;        // destination row is the lid row / the bottom row (wave-uniform)
+    bool l, r;        // this lane's element 0 is the left wall node / element V-1 the right wall node
+};
+
+// Streaming step towards one destination row, sources held in registers:
+//   A: populations (2,5,6) of the row below -- or, if fl.b, (4,7,8) of the destination row itself
+//   B: populations (0,1,3) of the destination row
+//   F: populations (4,7,8) of the row above (ignored if fl.t)
+//   TOP: populations (2,5,6) of the destination row (read only if fl.t)
+//   own7_l, own6_l: the destination row's populations 7 and 6 at the left wall node,
+//   own8_r, own5_r: its populations 8 and 5 at the right wall node (read by wall lanes only)
+// Result c[q] = population q arriving at the lane's V nodes.
+template <typename T, int V, bool LID, bool PUSH>
+__device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], const T (&B)[3][V],
+                                           const T (&F)[3][V], const T (&TOP)[3][V], const T own7_l,
+                                           const T own6_l, const T own8_r, const T own5_r,
+                                           const WallFlags fl, const T df_lid)
+{
+#pragma unroll
+    for (int i = 0; i < V; ++i) c[0][i] = B[0][i];
+    arrive_from_left<T, V>(c[1], B[1]);
+    arrive_from_right<T, V>(c[3], B[2]);
+    if (LID && fl.b) {
+        // bottom wall: 2 <- 4, 5 <- 7, 6 <- 8 of the node itself (pull-push.cpp:520,523,526)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { c[2][i] = A[0][i]; c[5][i] = A[1][i]; c[6][i] = A[2][i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) c[2][i] = A[0][i];
+        arrive_from_left<T, V>(c[5], A[1]);
+        arrive_from_right<T, V>(c[6], A[2]);
+        if (LID && PUSH) {
+            // the push form adds the (here zero) lid term to what it streams on (pull-push.cpp:522,528)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { c[6][i] = c[6][i] + T(0.); c[5][i] = c[5][i] - T(0.); }
+        }
+    }
+    if (LID && fl.t) {
+        // lid: 4 <- 2, 7 <- 5 - df, 8 <- 6 + df of the node itself (pull-push.cpp:522,525,528)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { c[4][i] = TOP[0][i]; c[7][i] = TOP[1][i] - df_lid; c[8][i] = TOP[2][i] + df_lid; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) c[4][i] = F[0][i];
+        arrive_from_right<T, V>(c[7], F[1]);
+        arrive_from_left<T, V>(c[8], F[2]);
+    }
+    if (LID) {
+        const T z = T(0.);
+        if (fl.l) {   // left wall: 1 <- 3, 5 <- 7, 8 <- 6 (+ zero lid term) of the node itself
+            c[1][0] = B[2][0];
+            if (!fl.b) c[5][0] = own7_l;
+            if (!fl.t) c[8][0] = own6_l + z;
+        }
+        if (fl.r) {   // right wall: 3 <- 1, 6 <- 8, 7 <- 5 (- zero lid term)
+            c[3][V - 1] = B[1][V - 1];
+            if (!fl.b) c[6][V - 1] = own8_r;
+            if (!fl.t) c[7][V - 1] = own5_r - z;
+        }
+    }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void relax_row(T (&o)[9][V], const T (&c)[9][V], const T om)
+{
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        T r[9];
+        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+    }
+}
+
+// One row of input as it sits in registers between its load and its use.
+template <typename T, int V>
+struct RowIn {
+    T v[9][V];      // pull: slots by destination population; push: the row's nine populations
+    T w[4];         // lid pull: own 7, own 6 at the left wall node; own 8, own 5 at the right wall node
+};
+
+// K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
+template <typename T, int V, int K, bool PUSH, bool LID>
+__global__ void __launch_bounds__(kWave)
+k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
+{
+    constexpr int H = kFusedHalo;
+    constexpr int W = kWave - 2 * H;         // vectors stored per strip
+    static_assert(H * V >= K, "x halo too narrow for K steps");
+    constexpr int NG = PUSH ? K : K - 1;     // streaming steps done in registers
+    constexpr int D = PUSH ? K : K - 1;      // rows between a segment's first row and the first row relaxed
+    constexpr int NR = NG > 0 ? NG : 1;
+
+    const uint32_t strip = blockIdx.x % g.nstrips;
+    const uint32_t seg = blockIdx.x / g.nstrips;
+    if (seg >= g.nsegs) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nxv = g.nx / V;
+    int64_t vx = (int64_t)strip * W - H + (int64_t)lane;
+    if (LID) {
+        // no wrap: lanes beyond a side wall read the wall vector; what they compute is never used
+        vx = vx < 0 ? 0 : (vx >= (int64_t)nxv ? (int64_t)nxv - 1 : vx);
+    } else {
+        vx %= (int64_t)nxv;
+        if (vx < 0) vx += nxv;
+    }
+    const uint32_t x0 = (uint32_t)vx * V;
+    const uint32_t wcount = min((uint32_t)W, nxv - strip * W);
+    const bool store_lane = lane >= (uint32_t)H && lane < H + wcount;
+    WallFlags fl0;
+    fl0.t = false; fl0.b = false;
+    fl0.l = LID && x0 == 0;
+    fl0.r = LID && x0 + V == g.nx;
+
+    const uint32_t ys = g.y_lo + seg * g.seg_rows;
+    const uint32_t ye = min(ys + g.seg_rows, g.y_hi);
+    const uint32_t iters = (ye - ys) + D + NG;
+    const size_t plane = (size_t)g.ny * g.nx;
+
+    // array row of lattice row R: wrapped for a periodic lattice, otherwise clamped into the array
+    // (clamped rows are only ever read for nodes outside the dependency cone of the stored rows)
+    auto row_index = [&](int64_t R) -> uint32_t {
+        if (g.wrap_y) {
+            R %= (int64_t)g.ny;
+            if (R < 0) R += g.ny;
+        } else {
+            R = R < 0 ? 0 : (R >= (int64_t)g.ny ? (int64_t)g.ny - 1 : R);
+        }
+        return (uint32_t)R;
+    };
+    auto wall_rows = [&](int64_t R, bool &t, bool &b) {
+        if (LID) {
+            const int64_t gy = R + g.y_goff;
+            b = gy == 0;
+            t = gy == (int64_t)g.ny_glob - 1;
+        } else {
+            t = false; b = false;
+        }
+    };
+
+    // iteration i relaxes row Rc = ys - D + i first
+    auto load_row = [&](RowIn<T, V> &d, uint32_t i) {
+        const int64_t Rc = (int64_t)ys - D + (int64_t)i;
+        const uint32_t y = row_index(Rc);
+        if (PUSH) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) load_a<T, V>(d.v[q], rowp(f, plane, q, y, g.nx) + x0);
+        } else {
+            const uint32_t yd = row_index(Rc - 1), yu = row_index(Rc + 1);
+            bool t, b;
+            wall_rows(Rc, t, b);
+            // pull-push.cpp:13-21; at the lid / the bottom wall the node's own populations instead
+            const T *p7 = t ? rowp(f, plane, 5, y, g.nx) : rowp(f, plane, 7, yu, g.nx);
+            const T *p4 = t ? rowp(f, plane, 2, y, g.nx) : rowp(f, plane, 4, yu, g.nx);
+            const T *p8 = t ? rowp(f, plane, 6, y, g.nx) : rowp(f, plane, 8, yu, g.nx);
+            const T *p6 = b ? rowp(f, plane, 8, y, g.nx) : rowp(f, plane, 6, yd, g.nx);
+            const T *p2 = b ? rowp(f, plane, 4, y, g.nx) : rowp(f, plane, 2, yd, g.nx);
+            const T *p5 = b ? rowp(f, plane, 7, y, g.nx) : rowp(f, plane, 5, yd, g.nx);
+            load_a<T, V>(d.v[7], p7 + x0);
+            load_a<T, V>(d.v[4], p4 + x0);
+            load_a<T, V>(d.v[8], p8 + x0);
+            load_a<T, V>(d.v[3], rowp(f, plane, 3, y, g.nx) + x0);
+            load_a<T, V>(d.v[0], rowp(f, plane, 0, y, g.nx) + x0);
+            load_a<T, V>(d.v[1], rowp(f, plane, 1, y, g.nx) + x0);
+            load_a<T, V>(d.v[6], p6 + x0);
+            load_a<T, V>(d.v[2], p2 + x0);
+            load_a<T, V>(d.v[5], p5 + x0);
+            if (LID) {   // same address in every lane: one request per wavefront
+                d.w[0] = rowp(f, plane, 7, y, g.nx)[0];
+                d.w[1] = rowp(f, plane, 6, y, g.nx)[0];
+                d.w[2] = rowp(f, plane, 8, y, g.nx)[g.nx - 1];
+                d.w[3] = rowp(f, plane, 5, y, g.nx)[g.nx - 1];
+            }
+        }
+    };
+
+    // per register-level streaming step: A = (2,5,6) two rows back, B = (0,1,3) one row back,
+    // C = (2,5,6) one row back, w7/w8 = populations 7 / 8 one row back at the wall nodes
+    T ringA[NR][3][V], ringB[NR][3][V], ringC[NR][3][V], ring7[NR], ring8[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { ringA[s][k][e] = T(1); ringB[s][k][e] = T(1); ringC[s][k][e] = T(1); }
+        ring7[s] = T(1); ring8[s] = T(1);
+    }
+
+    auto iteration = [&](const RowIn<T, V> &in, uint32_t i) {
+        const int64_t Rc = (int64_t)ys - D + (int64_t)i;
+        T o[9][V];
+        if (PUSH) {
+            relax_row<T, V>(o, in.v, om);
+        } else {
+            T A[3][V], B[3][V], F[3][V], c[9][V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                A[0][e] = in.v[2][e]; A[1][e] = in.v[5][e]; A[2][e] = in.v[6][e];
+                B[0][e] = in.v[0][e]; B[1][e] = in.v[1][e]; B[2][e] = in.v[3][e];
+                F[0][e] = in.v[4][e]; F[1][e] = in.v[7][e]; F[2][e] = in.v[8][e];
+            }
+            WallFlags fl = fl0;
+            wall_rows(Rc, fl.t, fl.b);
+            // at the lid the F slots were loaded with the row's own (2,5,6)
+            gather_row<T, V, LID, false>(c, A, B, F, F, in.w[0], in.w[1], in.w[2], in.w[3], fl, df_lid);
+            relax_row<T, V>(o, c, om);
+        }
+#pragma unroll
+        for (int s = 0; s < NG; ++s) {
+            const int64_t r = Rc - s;          // row held in o; destination row r - 1
+            T F[3][V], c[9][V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { F[0][e] = o[4][e]; F[1][e] = o[7][e]; F[2][e] = o[8][e]; }
+            WallFlags fl = fl0;
+            wall_rows(r - 1, fl.t, fl.b);
+            gather_row<T, V, LID, PUSH>(c, ringA[s], ringB[s], F, ringC[s], ring7[s], ringC[s][2][0],
+                                        ring8[s], ringC[s][1][V - 1], fl, df_lid);
+            // what the next rows need of row r
+            bool rt, rb;
+            wall_rows(r, rt, rb);
+            if (LID && rb) {
+                // row r is the bottom row: next iteration it bounces its own (4,7,8)
+#pragma unroll
+                for (int e = 0; e < V; ++e) { ringA[s][0][e] = o[4][e]; ringA[s][1][e] = o[7][e]; ringA[s][2][e] = o[8][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) { ringA[s][0][e] = ringC[s][0][e]; ringA[s][1][e] = ringC[s][1][e]; ringA[s][2][e] = ringC[s][2][e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                ringB[s][0][e] = o[0][e]; ringB[s][1][e] = o[1][e]; ringB[s][2][e] = o[3][e];
+                ringC[s][0][e] = o[2][e]; ringC[s][1][e] = o[5][e]; ringC[s][2][e] = o[6][e];
+            }
+            ring7[s] = o[7][0];
+            ring8[s] = o[8][V - 1];
+            if (PUSH && s == NG - 1) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[q][e] = c[q][e];
+            } else {
+                relax_row<T, V>(o, c, om);
+            }
+        }
+        if (i >= (uint32_t)(D + NG) && store_lane) {
+            const uint32_t yo = ys + i - (D + NG);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, yo, g.nx) + x0, o[q]);
+        }
+    };
+
+    RowIn<T, V> in0, in1;
+    load_row(in0, 0);
+    for (uint32_t i = 0; i < iters; i += 2) {
+        if (i + 1 < iters) load_row(in1, i + 1);
+        iteration(in0, i);
+        if (i + 1 < iters) {
+            if (i + 2 < iters) load_row(in0, i + 2);
+            iteration(in1, i + 1);
+        }
+    }
+}
+
+}  // namespace lbm

@@ -151,6 +151,39 @@ def pull_lid_rows(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob):
          float(rho_eq), float(u_lid), int(y_lo), int(y_hi), int(y_goff), int(ny_glob), _stream(f))
 
 
+# ---------------------------------------------------------------- several steps per call -----
+def fused_max_steps(f) -> int:
+    """Largest `nsteps` the fused sweeps accept for this array (1: rows are not whole 16-byte vectors)."""
+    nx, _ = _check_f(f)
+    return int(capi.load().lbm_fused_max_steps(_prec(f), nx))
+
+
+def pull_periodic_fused(f, buf, om, y_lo, y_hi, wrap_y, nsteps):
+    """`nsteps` iterations of the time loop (main.cpp:64-83) with pull_periodic for rows [y_lo, y_hi):
+    f holds time t, buf receives time t + nsteps."""
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_pull_periodic_fused", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(y_lo), int(y_hi), int(bool(wrap_y)), int(nsteps), _stream(f))
+
+
+def push_periodic_fused(f, buf, om, y_lo, y_hi, wrap_y, nsteps):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_push_periodic_fused", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         int(y_lo), int(y_hi), int(bool(wrap_y)), int(nsteps), _stream(f))
+
+
+def push_lid_fused(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, nsteps):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_push_lid_fused", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), int(y_lo), int(y_hi), int(y_goff), int(ny_glob), int(nsteps), _stream(f))
+
+
+def pull_lid_fused(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, nsteps):
+    nx, ny = _check_pair(f, buf)
+    _run("lbm_pull_lid_fused", f, f.data_ptr(), buf.data_ptr(), _prec(f), nx, ny, float(om),
+         float(rho_eq), float(u_lid), int(y_lo), int(y_hi), int(y_goff), int(ny_glob), int(nsteps), _stream(f))
+
+
 # ---------------------------------------------------------------- output path (io.cpp) -------
 def compute_velocities(vel, f, LX, LY, HX, HY):
     """compute_velocities (io.cpp:136-174).  vel: [2, HY-LY, NX] (ux plane, uy plane); the x range

@@ -1,0 +1,138 @@
+"""Several time steps per call (lbm_*_fused) against the CPU oracle stepped one step at a time.
+
+Bit-exact: the fused kernels run the same per-node arithmetic in the same order as the one-step
+sweeps, only the intermediate time levels stay in registers.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_parity_gpu import assert_bits_equal, TORCH
+
+pytestmark = pytest.mark.gpu
+
+RHO, U = 1.0, 0.1
+
+
+def random_state(rng, nx, ny, dtype):
+    return (1.0 / 9 + 0.02 * rng.standard_normal((9, ny, nx))).astype(dtype)
+
+
+def oracle_steps(name, f, k, om, dtype):
+    """k one-step oracle sweeps of a whole lattice with the buffers swapped in between."""
+    a = f.copy()
+    b = np.full_like(f, np.nan)
+    for _ in range(k):
+        if "lid" in name:
+            getattr(orc, name)(a, b, dtype(om), dtype(RHO), dtype(U))
+        else:
+            getattr(orc, name)(a, b, dtype(om))
+        a, b = b, a
+    return a
+
+
+ONE_STEP = {("shear", "pull"): "pull_periodic_no_mpi", ("shear", "push"): "push_periodic_no_mpi",
+            ("lid", "pull"): "pull_lid_driven", ("lid", "push"): "push_lid_driven"}
+
+
+def run_fused(scene, scheme, d_f, d_b, om, y_lo, y_hi, k, wrap_y=True, y_goff=0, ny_glob=None):
+    from lbm_amd import ops
+    if scene == "shear":
+        getattr(ops, f"{scheme}_periodic_fused")(d_f, d_b, om, y_lo, y_hi, wrap_y, k)
+    else:
+        getattr(ops, f"{scheme}_lid_fused")(d_f, d_b, om, RHO, U, y_lo, y_hi, y_goff, ny_glob, k)
+
+
+# row lengths: one strip, a partial last strip, several strips (a strip stores 60 vectors = 240
+# fp32 / 120 fp64 nodes), the shortest supported rows; heights: fewer rows than steps (multiple
+# wraps), one segment, several segments
+SIZES = [(8, 3), (8, 1), (64, 48), (240, 9), (244, 7), (1024, 70), (2048, 5), (4, 6), (724, 33)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,scheme", list(ONE_STEP))
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
+    from lbm_amd import ops
+    rng = np.random.default_rng(7 * k + (dtype == np.float64))
+    for nx, ny in SIZES:
+        if scene == "lid" and (ny < 2 or nx < 2):
+            continue
+        f = random_state(rng, nx, ny, dtype)
+        om = 1.3
+        want = oracle_steps(ONE_STEP[(scene, scheme)], f, k, om, dtype)
+        d_f = torch.from_numpy(f).cuda()
+        d_b = torch.full_like(d_f, float("nan"))
+        if ops.fused_max_steps(d_f) == 1:
+            continue   # rows shorter than two 16-byte vectors
+        run_fused(scene, scheme, d_f, d_b, om, 0, ny, k, wrap_y=True, y_goff=0, ny_glob=ny)
+        assert_bits_equal(d_b.cpu().numpy(), want, f"{scene}/{scheme} fused k={k} {nx}x{ny}")
+        assert torch.equal(d_f.cpu(), torch.from_numpy(f)), "the input array was modified"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_periodic_row_range_with_deep_ghost_rows(dtype, scheme, k):
+    """wrap_y = 0: rows [k, ny-k) advance from an array whose outer k rows are ghost rows; rows
+    outside the range must not be written."""
+    rng = np.random.default_rng(100 + k)
+    for nx, ny in ((256, 21), (1024, 40), (64, 2 * k + 1)):
+        f = random_state(rng, nx, ny, dtype)
+        want = oracle_steps(f"{scheme}_periodic_no_mpi", f, k, 0.8, dtype)
+        d_f = torch.from_numpy(f).cuda()
+        d_b = torch.full_like(d_f, -7.0)
+        run_fused("shear", scheme, d_f, d_b, 0.8, k, ny - k, k, wrap_y=False)
+        got = d_b.cpu().numpy()
+        assert_bits_equal(got[:, k:ny - k], want[:, k:ny - k], f"{scheme} rows k={k} {nx}x{ny}")
+        assert (got[:, :k] == -7.0).all() and (got[:, ny - k:] == -7.0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+@pytest.mark.parametrize("k", [2, 4])
+def test_lid_slab_of_a_taller_cavity(dtype, scheme, k):
+    """A slab holds global rows [g0 - ghosts, g1 + ghosts) of a cavity of height 40; slabs at the
+    bottom wall, in the middle and under the lid."""
+    rng = np.random.default_rng(200 + k)
+    nx, ny_glob = 256, 40
+    f = random_state(rng, nx, ny_glob, dtype)
+    want = oracle_steps(f"{scheme}_lid_driven", f, k, 1.6, dtype)
+    for g0, g1 in ((0, 13), (13, 27), (27, 40), (0, 40)):
+        lo = max(0, g0 - k)          # first global row present in the local array
+        hi = min(ny_glob, g1 + k)
+        local = np.ascontiguousarray(f[:, lo:hi])
+        d_f = torch.from_numpy(local).cuda()
+        d_b = torch.full_like(d_f, -7.0)
+        run_fused("lid", scheme, d_f, d_b, 1.6, g0 - lo, g1 - lo, k, y_goff=lo, ny_glob=ny_glob)
+        got = d_b.cpu().numpy()
+        assert_bits_equal(got[:, g0 - lo:g1 - lo], want[:, g0:g1], f"lid {scheme} k={k} rows {g0}:{g1}")
+        assert (got[:, :g0 - lo] == -7.0).all() and (got[:, g1 - lo:] == -7.0).all()
+
+
+def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
+    from lbm_amd import capi, ops
+    rng = np.random.default_rng(3)
+    f = random_state(rng, 64, 12, np.float32)
+    d_f = torch.from_numpy(f).cuda()
+    d_b = torch.zeros_like(d_f)
+    ops.pull_periodic_fused(d_f, d_b, 0.7, 0, 12, True, 1)
+    want = np.zeros_like(f)
+    orc.pull_periodic_no_mpi(f, want, np.float32(0.7))
+    assert_bits_equal(d_b.cpu().numpy(), want, "nsteps=1")
+    assert ops.fused_max_steps(d_f) == 4
+    odd = torch.zeros((9, 4, 66), dtype=torch.float64, device="cuda")
+    assert ops.fused_max_steps(odd) == 4
+    odd = torch.zeros((9, 4, 67), dtype=torch.float32, device="cuda")
+    assert ops.fused_max_steps(odd) == 1
+    with pytest.raises(capi.LbmError):
+        ops.pull_periodic_fused(odd, torch.zeros_like(odd), 0.7, 0, 4, True, 2)     # unsupported row length
+    with pytest.raises(capi.LbmError):
+        ops.pull_periodic_fused(d_f, d_b, 0.7, 0, 12, True, 5)                      # too many steps
+    with pytest.raises(capi.LbmError):
+        ops.push_periodic_fused(d_f, d_b, 0.7, 1, 11, False, 2)                     # ghost rows too shallow
+    with pytest.raises(capi.LbmError):
+        ops.push_lid_fused(d_f, d_b, 0.7, 1.0, 0.1, 1, 11, 5, 40, 2)                # ghost rows too shallow
+    with pytest.raises(capi.LbmError):
+        ops.pull_periodic_fused(d_f, d_f, 0.7, 0, 12, True, 2)                      # overlap
