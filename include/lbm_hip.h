@@ -59,7 +59,7 @@ int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu);
 
 /* Replaces init_shearwave (init.h:13, init.cpp:5-34).  Rows [halo, ny-halo) of f get the
  * equilibrium of ux = u*sinf(2*pi*(y-halo+y_below)/y_glob), uy = 0; halo is the reference's
- * USE_MPI offset (0 or 1, init.cpp:7-12).  The per-row equilibrium table is evaluated on the host
+ * USE_MPI offset (0 or 1 there, init.cpp:7-12; any ghost depth with 2*halo <= ny here).  The per-row equilibrium table is evaluated on the host
  * with libm sinf and double arithmetic exactly as init.cpp:57-84 spells it, then broadcast along x
  * on the device.  Synchronises the stream. */
 int lbm_init_shearwave(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, double u,
@@ -125,7 +125,10 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * (main.cpp:64-83 single rank: sweep, swap, sweep, ...; main.cpp:217-396 with halos) for rows
  * [y_lo, y_hi): it reads f at time t and leaves time t + nsteps in buf, bit-identical to nsteps calls
  * of the one-step entry point with the buffers swapped in between, while every population crosses
- * HBM once.  nsteps = 1 .. lbm_fused_max_steps(); 1 forwards to the one-step entry point.
+ * HBM once.  nsteps = 1 .. lbm_fused_max_steps().  Rows outside [y_lo, y_hi) of buf are not written
+ * (the one-step push entry points scatter into the neighbouring rows instead).  nsteps = 1 is
+ * forwarded to the one-step entry point, with its semantics, when the range is the whole lattice
+ * or the row length is not supported here.
  *
  * Rows that the dependency cone of the updated rows reaches must be present in the array: with
  * wrap_y = 0 the periodic forms read rows [y_lo - nsteps, y_hi + nsteps) (deep ghost rows: copies of
@@ -135,6 +138,13 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
 
 /* Largest nsteps the fused entry points accept for this precision and row length (1 = unsupported). */
 int lbm_fused_max_steps(int prec, uint64_t nx);
+
+/* How many of the `remaining` iterations of the time loop the next call should take for a lattice
+ * of `rows` rows of nx nodes: lbm_fused_max_steps() for lattices that stream from HBM, 1 for
+ * lattices small enough to stay in the on-die caches or not supported by the fused sweeps, never
+ * more than `remaining`.  The time loops of this library's drivers (main.cpp:64-83) ask this before
+ * every launch. */
+int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining);
 
 /* nsteps x pull_periodic (pull-push.cpp:5-73, :268-288). */
 int lbm_pull_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,

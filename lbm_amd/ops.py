@@ -158,6 +158,12 @@ def fused_max_steps(f) -> int:
     return int(capi.load().lbm_fused_max_steps(_prec(f), nx))
 
 
+def plan_steps(f, rows, remaining) -> int:
+    """Steps the next launch of the time loop should take (1 .. fused_max_steps, <= remaining)."""
+    nx, _ = _check_f(f)
+    return int(capi.load().lbm_plan_steps(_prec(f), nx, int(rows), int(remaining)))
+
+
 def pull_periodic_fused(f, buf, om, y_lo, y_hi, wrap_y, nsteps):
     """`nsteps` iterations of the time loop (main.cpp:64-83) with pull_periodic for rows [y_lo, y_hi):
     f holds time t, buf receives time t + nsteps."""

@@ -54,6 +54,7 @@ class Simulation:
         self.f = torch.empty((9, self.ny, self.nx), dtype=dtype, device=self.device)
         self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
         self.t = 0
+        self.launches = 0   # sweep launches so far (a launch advances 1..4 steps)
         self._vel: Optional[torch.Tensor] = None
         self._mag: Optional[torch.Tensor] = None
         if scene == LID_DRIVEN:
@@ -61,20 +62,35 @@ class Simulation:
         else:
             ops.init_shearwave(self.f, self.rho, self.u, 0, self.ny)
 
-    # -- one fused collide+stream step and the handle swap (main.cpp:71-84)
-    def step(self, n: int = 1) -> None:
-        for _ in range(n):
-            if self.scene == LID_DRIVEN:
-                if self.scheme == "push":
-                    ops.push_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
+    # -- n iterations of {one collide+stream sweep, handle swap} (main.cpp:71-84).  Lattices that
+    #    stream from HBM take up to `max_fuse` iterations per launch (same result, one pass over
+    #    memory); max_fuse=1 forces one launch per iteration.
+    def step(self, n: int = 1, max_fuse: Optional[int] = None) -> None:
+        n = int(n)
+        while n > 0:
+            k = ops.plan_steps(self.f, self.ny, n)
+            if max_fuse is not None:
+                k = max(1, min(k, int(max_fuse)))
+            if k == 1:
+                if self.scene == LID_DRIVEN:
+                    if self.scheme == "push":
+                        ops.push_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
+                    else:
+                        ops.pull_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
+                elif self.scheme == "push":
+                    ops.push_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
                 else:
-                    ops.pull_lid_driven(self.f, self.buf, self.nx, self.ny, self.omega, self.rho, self.u)
-            elif self.scheme == "push":
-                ops.push_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
+                    ops.pull_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
+            elif self.scene == LID_DRIVEN:
+                fused = ops.push_lid_fused if self.scheme == "push" else ops.pull_lid_fused
+                fused(self.f, self.buf, self.omega, self.rho, self.u, 0, self.ny, 0, self.ny, k)
             else:
-                ops.pull_periodic_no_mpi(self.f, self.buf, self.nx, self.ny, self.omega)
+                fused = ops.push_periodic_fused if self.scheme == "push" else ops.pull_periodic_fused
+                fused(self.f, self.buf, self.omega, 0, self.ny, True, k)
             self.f, self.buf = self.buf, self.f
-            self.t += 1
+            self.t += k
+            self.launches += 1
+            n -= k
 
     def max_velocity(self) -> float:
         return ops.max_velocity(self.f)
@@ -111,10 +127,14 @@ class Simulation:
         """The reference's main loop: output before the step when t % out_every == 0."""
         own = stream is None
         stream = _io.StringIO() if own else stream
-        for t in range(steps):
+        t = 0
+        while t < steps:
             if out_every > 0 and t % out_every == 0:
                 self.output(kind, stream)
-            self.step()
+            # up to the next output (or the end) in one go
+            nxt = min(steps, (t // out_every + 1) * out_every) if out_every > 0 else steps
+            self.step(nxt - t)
+            t = nxt
         return stream.getvalue() if own else ""
 
 

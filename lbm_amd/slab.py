@@ -8,6 +8,14 @@ pair is already contiguous, so the three populations that cross a slab edge are 
 / received straight into the population array: no pack or unpack kernels (the reference needs six,
 main.cpp:238-273, :339-374).
 
+Two schedules share this layout.  Lattices that stream from HBM (and whose rows are whole 16-byte
+vectors) run the deep-halo schedule: G = 4 ghost rows per side hold plain copies of the neighbour's
+edge rows, a block of up to G time steps is advanced by one fused launch per region (see
+csrc/lbm_fused.h: every population crosses HBM once per block, not once per step), and ghost rows
+are refreshed once per block -- nine contiguous G-row messages per direction.  Everything else
+runs the one-row schedule described next.  In both, the interior and the edge regions of a slab
+are advanced on two streams so that the exchange hides behind the interior update.
+
 Per step, two streams run side by side.  The edge stream updates rows 1 and n and then exchanges
 halo rows with the neighbours (RCCL send/recv over xGMI when the backend is "nccl"); the interior
 stream updates rows 2..n-1.  The interior sweep of step t+1 needs only the interior and edge
@@ -53,8 +61,19 @@ class HipBackend:
         from . import ops
         self.ops = ops
 
-    def init_shearwave(self, f, rho, u, y_below, y_glob):
-        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=1)
+    def init_shearwave(self, f, rho, u, y_below, y_glob, halo=1):
+        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=halo)
+
+    def plan_steps(self, f, rows, remaining):
+        return self.ops.plan_steps(f, rows, remaining)
+
+    def periodic_fused(self, scheme, f, buf, om, y_lo, y_hi, k):
+        fn = self.ops.pull_periodic_fused if scheme == "pull" else self.ops.push_periodic_fused
+        fn(f, buf, om, y_lo, y_hi, False, k)
+
+    def lid_fused(self, scheme, f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob, k):
+        fn = self.ops.pull_lid_fused if scheme == "pull" else self.ops.push_lid_fused
+        fn(f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob, k)
 
     def init_rest(self, f, rho):
         self.ops.init_rest(f, rho)
@@ -106,7 +125,7 @@ class SlabSimulation:
     def __init__(self, nx: int, ny_glob: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
                  dtype: torch.dtype = torch.float32, omega: float = 0.5, rho: float = 1.0,
                  u: float = 0.1, device="cuda:0", backend=None, group=None, overlap: bool = True,
-                 p2p_to_self: bool = False):
+                 p2p_to_self: bool = False, halo: Optional[int] = None):
         if scene not in (SHEAR_WAVE, LID_DRIVEN):
             raise ValueError(f"unknown scene {scene!r}")
         if scheme not in ("pull", "push"):
@@ -138,12 +157,28 @@ class SlabSimulation:
         self.upper: Optional[int] = (self.rank + 1) % self.world if (self.periodic or self.rank < self.world - 1) else None
 
         n = self.n
-        self.f = torch.empty((9, n + 2, self.nx), dtype=dtype, device=self.device)
+        # Ghost depth G.  halo=None: ask the library how many steps one launch should take for a
+        # slab of the smallest rank's height (every rank must arrive at the same answer); a depth
+        # above 1 selects the deep-halo schedule and needs slabs of at least 2G rows.
+        if halo is None:
+            probe = torch.empty((9, 1, self.nx), dtype=dtype, device=self.device)
+            n_min = self.ny_glob // self.world
+            halo = int(backend.plan_steps(probe, n_min, 1 << 30)) if hasattr(backend, "plan_steps") else 1
+            if n_min < 2 * halo:
+                halo = 1
+        self.G = G = int(halo)
+        if G < 1:
+            raise ValueError(f"halo depth must be positive (got {halo})")
+        if G > 1 and self.ny_glob // self.world < 2 * G:
+            raise ValueError(f"halo depth {G} needs slabs of at least {2 * G} rows")
+        self.deep = G > 1
+        self.f = torch.empty((9, n + 2 * G, self.nx), dtype=dtype, device=self.device)
         self.buf = torch.empty_like(self.f)
-        # ghost rows start defined (a wall-side ghost row is never read by the lid kernels, a
+        # ghost rows start defined (a wall-side ghost row is never used by the lid kernels, a
         # periodic one is overwritten by the first exchange)
-        self.f[:, 0].zero_(); self.f[:, n + 1].zero_()
-        self.buf[:, 0].zero_(); self.buf[:, n + 1].zero_()
+        self.f[:, :G].zero_(); self.f[:, n + G:].zero_()
+        self.buf[:, :G].zero_(); self.buf[:, n + G:].zero_()
+        self.blocks = 0     # exchanges so far = launches of the interior sweep
         self._max = torch.empty(2, dtype=dtype, device=self.device)
         self.t = 0
 
@@ -172,14 +207,19 @@ class SlabSimulation:
 
         if scene == LID_DRIVEN:
             backend.init_rest(self.f, self.rho)
+        elif self.deep:
+            backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob, halo=G)
         else:
             backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob)
-        if self.scheme == "pull":
+        if self.deep or self.scheme == "pull":
             # pull reads ghost rows of f: fill them from the neighbours' initial edge rows
             if self.overlap:
                 self._interior_done[1].record(self.compute_stream)   # initialisation finished
                 self.comm_stream.wait_event(self._interior_done[1])
-            self._exchange(self.f, pull=True)
+            if self.deep:
+                self._exchange_deep(self.f)
+            else:
+                self._exchange(self.f, pull=True)
             self._join_halo()
 
     # ------------------------------------------------------------------ exchange -------------
@@ -246,6 +286,81 @@ class SlabSimulation:
                 self._halo_done.record(self.comm_stream)
         self._halo_pending = True
 
+    def _exchange_deep(self, a: torch.Tensor) -> None:
+        """Deep-halo exchange on array `a` (edge/communication stream): my G lowest and G highest
+        rows, all nine populations, become the neighbours' ghost rows.  A [G, NX] block of one
+        population is contiguous, so it is sent and received in place."""
+        n, G = self.n, self.G
+        lo_own, hi_own = slice(G, 2 * G), slice(n, n + G)          # rows I send down / up
+        lo_ghost, hi_ghost = slice(0, G), slice(n + G, n + 2 * G)   # rows I receive from below / above
+        ctx = torch.cuda.stream(self.comm_stream) if self.cuda else _NullCtx()
+        with ctx:
+            if self.world == 1 and not self.p2p_to_self:
+                if self.lower is not None:  # periodic: the neighbour is this rank itself
+                    a[:, hi_ghost].copy_(a[:, lo_own])
+                    a[:, lo_ghost].copy_(a[:, hi_own])
+            else:
+                # same pairing rule as _exchange: sends [down, up], receives [from above, from below]
+                p2p: List[dist.P2POp] = []
+                if self.lower is not None:
+                    for q in range(9):
+                        p2p.append(dist.P2POp(dist.isend, a[q, lo_own], self._peer(self.lower), self.group, tag=q))
+                if self.upper is not None:
+                    for q in range(9):
+                        p2p.append(dist.P2POp(dist.isend, a[q, hi_own], self._peer(self.upper), self.group, tag=q))
+                if self.upper is not None:
+                    for q in range(9):
+                        p2p.append(dist.P2POp(dist.irecv, a[q, hi_ghost], self._peer(self.upper), self.group, tag=q))
+                if self.lower is not None:
+                    for q in range(9):
+                        p2p.append(dist.P2POp(dist.irecv, a[q, lo_ghost], self._peer(self.lower), self.group, tag=q))
+                if p2p:
+                    if not self.stream_ordered:
+                        (self.comm_stream if self.overlap else self.compute_stream).synchronize()
+                    for req in dist.batch_isend_irecv(p2p):
+                        req.wait()
+            if self.cuda and self.overlap:
+                self._halo_done.record(self.comm_stream)
+        self._halo_pending = True
+
+    def _sweep_fused(self, y_lo: int, y_hi: int, k: int) -> None:
+        if y_lo >= y_hi:
+            return
+        b = self.backend
+        if self.scene == LID_DRIVEN:
+            b.lid_fused(self.scheme, self.f, self.buf, self.omega, self.rho, self.u, y_lo, y_hi,
+                        self.y_below - self.G, self.ny_glob, k)
+        else:
+            b.periodic_fused(self.scheme, self.f, self.buf, self.omega, y_lo, y_hi, k)
+
+    def _block(self, k: int) -> None:
+        """Advance k <= G time steps: edge regions (G rows at either end) and the exchange on the
+        edge stream, the interior on the compute stream.  The interior of a block reads owned rows
+        only, so it never waits for an exchange; it needs the previous block's edge rows, and the
+        edge regions need the previous block's interior rows and exchange."""
+        n, G = self.n, self.G
+        if self.overlap:
+            c = self.blocks & 1
+            p = c ^ 1
+            self.comm_stream.wait_event(self._interior_done[p])
+            self.compute_stream.wait_event(self._edges_done[p])
+            # interior first: see step()
+            self._sweep_fused(2 * G, n, k)
+            self._interior_done[c].record(self.compute_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self._sweep_fused(G, 2 * G, k)
+                self._sweep_fused(n, n + G, k)
+                self._edges_done[c].record(self.comm_stream)
+            self._exchange_deep(self.buf)
+        else:
+            self._sweep_fused(G, 2 * G, k)
+            self._sweep_fused(n, n + G, k)
+            self._exchange_deep(self.buf)
+            self._sweep_fused(2 * G, n, k)
+        self.f, self.buf = self.buf, self.f
+        self.blocks += 1
+        self.t += k
+
     def _peer(self, group_rank: int) -> int:
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
@@ -271,6 +386,13 @@ class SlabSimulation:
     def step(self, nsteps: int = 1) -> None:
         n = self.n
         pull = self.scheme == "pull"
+        if self.deep:
+            nsteps = int(nsteps)
+            while nsteps > 0:
+                k = min(self.G, nsteps)
+                self._block(k)
+                nsteps -= k
+            return
         for _ in range(nsteps):
             if self.overlap:
                 k = self.t & 1
@@ -300,12 +422,13 @@ class SlabSimulation:
                 self._sweep(2, n)
             self.f, self.buf = self.buf, self.f
             self.t += 1
+            self.blocks += 1
 
     # ------------------------------------------------------------------ observables ----------
     def max_velocity(self) -> float:
         """Global max |u| (reference io.cpp:184-216: local reduce, then MPI_Reduce(MAX))."""
         self._join_halo()
-        self.backend.max_velocity_dev(self._max, self.f, 1, self.n + 1)
+        self.backend.max_velocity_dev(self._max, self.f, self.G, self.G + self.n)
         if self.world > 1:
             if not self.stream_ordered:
                 torch.cuda.synchronize(self.device)
@@ -315,7 +438,7 @@ class SlabSimulation:
     def interior(self) -> torch.Tensor:
         """This rank's rows without the ghost rows: [9, n, NX] (a view)."""
         self._join_halo()
-        return self.f[:, 1:self.n + 1]
+        return self.f[:, self.G:self.G + self.n]
 
     def gather_populations(self) -> Optional[torch.Tensor]:
         """Rank 0 gets the global [9, NY, NX] populations (for tests / small outputs)."""

@@ -6,12 +6,59 @@ from oracle import oracle as orc
 
 
 class OracleBackend:
-    def init_shearwave(self, f, rho, u, y_below, y_glob):
+    # steps per launch that SlabSimulation(halo=None) would be told to take; tests set it to pick
+    # the one-row (1) or the deep-halo (> 1) schedule
+    fused_depth = 1
+
+    def init_shearwave(self, f, rho, u, y_below, y_glob, halo=1):
         a = f.numpy()
-        interior = np.ascontiguousarray(a[:, 1:-1])
+        interior = np.ascontiguousarray(a[:, halo:a.shape[1] - halo])
         t = a.dtype.type
         orc.init_shearwave(interior, t(rho), t(u), y_below, y_glob)
-        a[:, 1:-1] = interior
+        a[:, halo:a.shape[1] - halo] = interior
+
+    def plan_steps(self, f, rows, remaining):
+        return min(self.fused_depth, remaining)
+
+    # k steps of rows [y_lo, y_hi) from an array with >= k ghost rows: step j advances rows
+    # [y_lo-(k-j), y_hi+(k-j)), one oracle sweep at a time.  The push sweep scatters, so it is run
+    # on one more row at either end (inside a copy padded by one row) and only complete rows are kept.
+    def _fused(self, one_step, f, buf, y_lo, y_hi, k, clip_lo, clip_hi):
+        a = f.numpy()
+        ny = a.shape[1]
+        cur = np.zeros((9, ny + 2, a.shape[2]), dtype=a.dtype)
+        cur[:, 1:ny + 1] = a
+        for j in range(1, k + 1):
+            lo = max(y_lo - (k - j), clip_lo)
+            hi = min(y_hi + (k - j), clip_hi)
+            nxt = np.zeros_like(cur)
+            one_step(cur, nxt, lo + 1, hi + 1)      # +1: row index inside the padded copy
+            keep = np.zeros_like(cur)
+            keep[:, lo + 1:hi + 1] = nxt[:, lo + 1:hi + 1]
+            cur = keep
+        buf.numpy()[:, y_lo:y_hi] = cur[:, y_lo + 1:y_hi + 1]
+
+    def periodic_fused(self, scheme, f, buf, om, y_lo, y_hi, k):
+        t = f.numpy().dtype.type
+        ny = f.shape[1]
+        if scheme == "pull":
+            step = lambda a, b, lo, hi: orc.pull_rows(a, b, t(om), lo, hi, False)
+        else:
+            step = lambda a, b, lo, hi: orc.push_rows(a, b, t(om), max(lo - 1, 1), min(hi + 1, ny + 1), False)
+        self._fused(step, f, buf, y_lo, y_hi, k, 0, ny)
+
+    def lid_fused(self, scheme, f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob, k):
+        t = f.numpy().dtype.type
+        ny = f.shape[1]
+        # rows of the local array that lie inside the cavity
+        clip_lo, clip_hi = max(0, -y_goff), min(ny, ny_glob - y_goff)
+        goff = y_goff - 1   # global row of padded row 0
+        if scheme == "pull":
+            step = lambda a, b, lo, hi: orc.pull_lid_rows(a, b, t(om), t(rho), t(u), lo, hi, goff, ny_glob)
+        else:
+            step = lambda a, b, lo, hi: orc.push_lid_rows(a, b, t(om), t(rho), t(u), max(lo - 1, clip_lo + 1),
+                                                          min(hi + 1, clip_hi + 1), goff, ny_glob)
+        self._fused(step, f, buf, y_lo, y_hi, k, clip_lo, clip_hi)
 
     def init_rest(self, f, rho):
         a = f.numpy()

@@ -61,12 +61,21 @@ def test_populations_match_oracle_bit_for_bit(dtype, scene, scheme, nx, ny):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scene,scheme", CASES)
-def test_long_run_1000_steps(dtype, scene, scheme):
+def test_long_run_1000_steps(dtype, scene, scheme, monkeypatch):
     nx, ny, omega = 128, 96, 0.5
+    ref, _ = orc.run(scene, scheme, nx, ny, 1000, omega, dtype)
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
-    ref, _ = orc.run(scene, scheme, nx, ny, 1000, omega, dtype)
     assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps")
+    # the same run with the time loop told to fuse steps even on this small lattice
+    monkeypatch.setenv("LBM_FUSED_MIN_NODES", "0")
+    sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
+    sim.step(1000)
+    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches")
+    monkeypatch.setenv("LBM_FUSED_MAX_STEPS", "3")
+    sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
+    sim.step(1000)
+    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 3")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -183,10 +192,12 @@ def test_slab_simulation_single_rank_equals_plain_simulation():
     for scene, scheme in CASES:
         for dtype in (torch.float32, torch.float64):
             a = Simulation(256, 40, scene=scene, scheme=scheme, dtype=dtype, omega=1.1)
-            b = SlabSimulation(256, 40, scene=scene, scheme=scheme, dtype=dtype, omega=1.1)
-            a.step(37); b.step(37)
-            assert torch.equal(a.f, b.interior()), (scene, scheme, dtype)
-            assert a.max_velocity() == b.max_velocity()
+            a.step(37)
+            for halo in (1, 2, 4):   # one halo row per step; deep halos with fused blocks of steps
+                b = SlabSimulation(256, 40, scene=scene, scheme=scheme, dtype=dtype, omega=1.1, halo=halo)
+                b.step(37)
+                assert torch.equal(a.f, b.interior()), (scene, scheme, dtype, halo)
+                assert a.max_velocity() == b.max_velocity()
 
 
 def test_invalid_arguments_are_rejected():

@@ -30,15 +30,18 @@ def _worker(rank, world, store_path, cases, out_path):
     dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
     results = {}
     try:
-        for (scene, scheme, tdt, nx, ny, steps, omega) in cases:
+        for (scene, scheme, tdt, nx, ny, steps, omega, depth) in cases:
+            backend = OracleBackend()
+            backend.fused_depth = depth
             sim = SlabSimulation(nx, ny, scene=scene, scheme=scheme, dtype=getattr(torch, tdt), omega=omega,
-                                 device="cpu", backend=OracleBackend())
+                                 device="cpu", backend=backend)
+            assert sim.G == depth and sim.deep == (depth > 1)
             vmax0 = sim.max_velocity()
             sim.step(steps)
             vmax = sim.max_velocity()
             full = sim.gather_populations()
             if rank == 0:
-                results[(scene, scheme, tdt, nx, ny, steps, omega)] = (full.numpy().copy(), vmax0, vmax)
+                results[(scene, scheme, tdt, nx, ny, steps, omega, depth)] = (full.numpy().copy(), vmax0, vmax)
         if rank == 0:
             torch.save(results, out_path)
     finally:
@@ -46,15 +49,24 @@ def _worker(rank, world, store_path, cases, out_path):
         dist.destroy_process_group()
 
 
+# (scene, scheme, dtype, nx, ny, steps, omega, ghost depth): depth 1 = one halo row exchanged per
+# step, depth > 1 = the deep-halo schedule (blocks of `depth` steps, the last block shorter)
 CASES = [
-    ("shear", "pull", "float32", 16, 13, 25, 0.8),
-    ("shear", "push", "float32", 16, 13, 25, 0.8),
-    ("shear", "pull", "float64", 12, 10, 40, 1.3),
-    ("shear", "push", "float64", 12, 10, 40, 1.3),
-    ("lid", "push", "float64", 12, 11, 60, 1.1),
-    ("lid", "pull", "float64", 12, 11, 60, 1.1),
-    ("lid", "push", "float32", 8, 7, 30, 1.7),
-    ("shear", "pull", "float64", 8, 4, 10, 0.5),     # some ranks own a single row
+    ("shear", "pull", "float32", 16, 13, 25, 0.8, 1),
+    ("shear", "push", "float32", 16, 13, 25, 0.8, 1),
+    ("shear", "pull", "float64", 12, 10, 40, 1.3, 1),
+    ("shear", "push", "float64", 12, 10, 40, 1.3, 1),
+    ("lid", "push", "float64", 12, 11, 60, 1.1, 1),
+    ("lid", "pull", "float64", 12, 11, 60, 1.1, 1),
+    ("lid", "push", "float32", 8, 7, 30, 1.7, 1),
+    ("shear", "pull", "float64", 8, 4, 10, 0.5, 1),     # some ranks own a single row
+    ("shear", "pull", "float32", 16, 25, 26, 0.8, 4),
+    ("shear", "push", "float32", 16, 25, 26, 0.8, 4),
+    ("shear", "pull", "float64", 12, 24, 9, 1.3, 4),    # slabs of exactly 2 x depth rows (world 3)
+    ("shear", "push", "float64", 12, 19, 17, 1.3, 3),
+    ("lid", "push", "float64", 12, 26, 31, 1.1, 4),
+    ("lid", "pull", "float64", 12, 26, 31, 1.1, 4),
+    ("lid", "push", "float32", 8, 13, 30, 1.7, 2),
 ]
 
 
@@ -66,7 +78,7 @@ def test_slabs_reproduce_the_single_domain_run(world):
         mp.spawn(_worker, args=(world, store, CASES, out), nprocs=world, join=True)
         results = torch.load(out, weights_only=False)
     for case in CASES:
-        scene, scheme, tdt, nx, ny, steps, omega = case
+        scene, scheme, tdt, nx, ny, steps, omega, _depth = case
         got, vmax0, vmax = results[case]
         ndt = np.float32 if tdt == "float32" else np.float64
         want, _ = orc.run(scene, scheme, nx, ny, steps, omega, ndt)
@@ -94,13 +106,17 @@ def test_single_process_world_of_one_uses_self_exchange():
     from lbm_amd.slab import SlabSimulation
     from slab_backend import OracleBackend
     from oracle import oracle as orc
-    for scene, scheme in (("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")):
-        sim = SlabSimulation(10, 9, scene=scene, scheme=scheme, dtype=torch.float64, omega=0.9,
-                             device="cpu", backend=OracleBackend())
-        sim.step(15)
-        want, _ = orc.run(scene, scheme, 10, 9, 15, 0.9, np.float64)
-        assert np.array_equal(sim.interior().numpy(), want), (scene, scheme)
-        assert sim.max_velocity() == float(orc.max_velocity(want))
+    for depth in (1, 4):
+        for scene, scheme in (("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")):
+            backend = OracleBackend()
+            backend.fused_depth = depth
+            sim = SlabSimulation(10, 9, scene=scene, scheme=scheme, dtype=torch.float64, omega=0.9,
+                                 device="cpu", backend=backend)
+            assert sim.G == depth
+            sim.step(15)
+            want, _ = orc.run(scene, scheme, 10, 9, 15, 0.9, np.float64)
+            assert np.array_equal(sim.interior().numpy(), want), (scene, scheme, depth)
+            assert sim.max_velocity() == float(orc.max_velocity(want))
 
 
 def test_cpu_device_without_backend_is_refused():

@@ -33,13 +33,14 @@ def _worker(rank, world, store_path, out_path):
     try:
         for case in CASES:
             scene, scheme, tdt, nx, ny, steps, omega = case
-            sim = SlabSimulation(nx, ny, scene=scene, scheme=scheme, dtype=getattr(torch, tdt), omega=omega,
-                                 device="cuda:0")
-            sim.step(steps)
-            vmax = sim.max_velocity()
-            full = sim.gather_populations()
-            if rank == 0:
-                results[case] = (full.cpu().numpy(), vmax)
+            for halo in (1, 4):   # one halo row per step / deep halo, blocks of four fused steps
+                sim = SlabSimulation(nx, ny, scene=scene, scheme=scheme, dtype=getattr(torch, tdt), omega=omega,
+                                     device="cuda:0", halo=halo)
+                sim.step(steps)
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[case + (halo,)] = (full.cpu().numpy(), vmax)
         if rank == 0:
             torch.save(results, out_path)
     finally:
@@ -57,10 +58,11 @@ def _worker_big(rank, world, store_path, out_dir):
     dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
     ok = True
     try:
-        for scheme, overlap in (("pull", True), ("push", True), ("pull", False)):
-            nx, ny, steps, omega = 8192, 1024, 12, 0.5
+        for scheme, overlap, halo in (("pull", True, 1), ("push", True, 1), ("pull", False, 1),
+                                      ("pull", True, 4), ("push", True, 4), ("push", False, 4)):
+            nx, ny, steps, omega = 8192, 1024, 14, 0.5
             sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=torch.float32, omega=omega,
-                                 device="cuda:0", overlap=overlap)
+                                 device="cuda:0", overlap=overlap, halo=halo)
             sim.step(steps)
             vmax = sim.max_velocity()
             want, _ = orc.run("shear", scheme, 8, ny, steps, omega, np.float32)
@@ -93,13 +95,17 @@ def _worker_rccl_self(rank, world, port, out_dir):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     ok = True
     try:
-        for scheme, tdt, ndt, nx, ny in (("pull", torch.float32, np.float32, 8192, 512),
-                                         ("push", torch.float32, np.float32, 8192, 512),
-                                         ("pull", torch.float64, np.float64, 4096, 256),
-                                         ("push", torch.float64, np.float64, 1030, 64)):
+        for scheme, tdt, ndt, nx, ny, halo in (("pull", torch.float32, np.float32, 8192, 512, 1),
+                                               ("push", torch.float32, np.float32, 8192, 512, 1),
+                                               ("pull", torch.float64, np.float64, 4096, 256, 1),
+                                               ("push", torch.float64, np.float64, 1030, 64, 1),
+                                               ("pull", torch.float32, np.float32, 8192, 512, 4),
+                                               ("push", torch.float32, np.float32, 8192, 512, 4),
+                                               ("pull", torch.float64, np.float64, 4096, 256, 4),
+                                               ("push", torch.float64, np.float64, 1030, 64, 3)):
             steps, omega = 15, 0.7
             sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=tdt, omega=omega, device="cuda:0",
-                                 p2p_to_self=True)
+                                 p2p_to_self=True, halo=halo)
             assert sim.stream_ordered and sim.overlap
             sim.step(steps)
             vmax = sim.max_velocity()
@@ -132,8 +138,9 @@ def test_two_ranks_on_one_gpu_reproduce_the_oracle():
         results = torch.load(out, weights_only=False)
     for case in CASES:
         scene, scheme, tdt, nx, ny, steps, omega = case
-        got, vmax = results[case]
         ndt = np.float32 if tdt == "float32" else np.float64
         want, _ = orc.run(scene, scheme, nx, ny, steps, omega, ndt)
-        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), case
-        assert vmax == float(orc.max_velocity(want)), case
+        for halo in (1, 4):
+            got, vmax = results[case + (halo,)]
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (case, halo)
+            assert vmax == float(orc.max_velocity(want)), (case, halo)
