@@ -108,33 +108,35 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
                                            const WallFlags fl, const T df_lid)
 {
 #pragma unroll
-    for (int i = 0; i < V; ++i) c[0][i] = B[0][i];
+    for (int i = 0; i < V; ++i) { c[0][i] = B[0][i]; c[2][i] = A[0][i]; }
     arrive_from_left<T, V>(c[1], B[1]);
     arrive_from_right<T, V>(c[3], B[2]);
-    if (LID && fl.b) {
-        // bottom wall: 2 <- 4, 5 <- 7, 6 <- 8 of the node itself (pull-push.cpp:520,523,526)
+    // the diagonal and vertical movers as they stream in from the rows below and above
+    T s5[V], s6[V], s7[V], s8[V];
+    arrive_from_left<T, V>(s5, A[1]);
+    arrive_from_right<T, V>(s6, A[2]);
+    arrive_from_right<T, V>(s7, F[1]);
+    arrive_from_left<T, V>(s8, F[2]);
+    if (LID && PUSH) {
+        // the push form adds the (here zero) lid term to what it streams on (pull-push.cpp:522,528)
 #pragma unroll
-        for (int i = 0; i < V; ++i) { c[2][i] = A[0][i]; c[5][i] = A[1][i]; c[6][i] = A[2][i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) c[2][i] = A[0][i];
-        arrive_from_left<T, V>(c[5], A[1]);
-        arrive_from_right<T, V>(c[6], A[2]);
-        if (LID && PUSH) {
-            // the push form adds the (here zero) lid term to what it streams on (pull-push.cpp:522,528)
-#pragma unroll
-            for (int i = 0; i < V; ++i) { c[6][i] = c[6][i] + T(0.); c[5][i] = c[5][i] - T(0.); }
-        }
+        for (int i = 0; i < V; ++i) { s6[i] = s6[i] + T(0.); s5[i] = s5[i] - T(0.); }
     }
-    if (LID && fl.t) {
-        // lid: 4 <- 2, 7 <- 5 - df, 8 <- 6 + df of the node itself (pull-push.cpp:522,525,528)
+    if (!LID || !(fl.t || fl.b)) {
 #pragma unroll
-        for (int i = 0; i < V; ++i) { c[4][i] = TOP[0][i]; c[7][i] = TOP[1][i] - df_lid; c[8][i] = TOP[2][i] + df_lid; }
+        for (int i = 0; i < V; ++i) { c[5][i] = s5[i]; c[6][i] = s6[i]; c[4][i] = F[0][i]; c[7][i] = s7[i]; c[8][i] = s8[i]; }
     } else {
+        // bottom wall: 2 <- 4 (already in A[0]), 5 <- 7, 6 <- 8 of the node itself (pull-push.cpp:520,
+        // 523,526); lid: 4 <- 2, 7 <- 5 - df, 8 <- 6 + df of the node itself (:522,525,528).  Selects on
+        // wave-uniform flags keep every element in its register.
 #pragma unroll
-        for (int i = 0; i < V; ++i) c[4][i] = F[0][i];
-        arrive_from_right<T, V>(c[7], F[1]);
-        arrive_from_left<T, V>(c[8], F[2]);
+        for (int i = 0; i < V; ++i) {
+            c[5][i] = fl.b ? A[1][i] : s5[i];
+            c[6][i] = fl.b ? A[2][i] : s6[i];
+            c[4][i] = fl.t ? TOP[0][i] : F[0][i];
+            c[7][i] = fl.t ? TOP[1][i] - df_lid : s7[i];
+            c[8][i] = fl.t ? TOP[2][i] + df_lid : s8[i];
+        }
     }
     if (LID) {
         const T z = T(0.);
@@ -202,6 +204,8 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
     fl0.t = false; fl0.b = false;
     fl0.l = LID && x0 == 0;
     fl0.r = LID && x0 + V == g.nx;
+    // does any lane of this wavefront sit at a side wall (wave-uniform)?
+    const bool wall_wave = LID && __ballot(fl0.l || fl0.r) != 0;
 
     const uint32_t ys = g.y_lo + seg * g.seg_rows;
     const uint32_t ye = min(ys + g.seg_rows, g.y_hi);
@@ -256,11 +260,14 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
             load_a<T, V>(d.v[6], p6 + x0);
             load_a<T, V>(d.v[2], p2 + x0);
             load_a<T, V>(d.v[5], p5 + x0);
-            if (LID) {   // same address in every lane: one request per wavefront
-                d.w[0] = rowp(f, plane, 7, y, g.nx)[0];
-                d.w[1] = rowp(f, plane, 6, y, g.nx)[0];
-                d.w[2] = rowp(f, plane, 8, y, g.nx)[g.nx - 1];
-                d.w[3] = rowp(f, plane, 5, y, g.nx)[g.nx - 1];
+            if (LID && wall_wave) {
+                // the row's own populations at the wall nodes, for the wall lanes: element 0 of a
+                // left-wall lane is x = 0, element V-1 of a right-wall lane x = nx-1.  Per-lane
+                // addresses keep these on the vector memory path next to the nine row loads.
+                d.w[0] = rowp(f, plane, 7, y, g.nx)[x0];
+                d.w[1] = rowp(f, plane, 6, y, g.nx)[x0];
+                d.w[2] = rowp(f, plane, 8, y, g.nx)[x0 + V - 1];
+                d.w[3] = rowp(f, plane, 5, y, g.nx)[x0 + V - 1];
             }
         }
     };
@@ -341,6 +348,8 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
     };
 
     RowIn<T, V> in0, in1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { in0.w[k] = T(0); in1.w[k] = T(0); }
     load_row(in0, 0);
     for (uint32_t i = 0; i < iters; i += 2) {
         if (i + 1 < iters) load_row(in1, i + 1);
