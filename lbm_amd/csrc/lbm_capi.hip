@@ -378,10 +378,12 @@ unsigned fused_seg_rows_default()
 }
 unsigned g_fused_seg_rows = fused_seg_rows_default();
 
+template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
+
 template <typename T>
 bool fused_supported(uint64_t nx)
 {
-    constexpr int V = vec_width<T>();
+    constexpr int V = fused_width<T>();
     return nx % V == 0 && nx >= 2 * V;
 }
 
@@ -391,7 +393,7 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
                 hipStream_t stream)
 {
     if (y_lo == y_hi) return LBM_OK;
-    constexpr int V = vec_width<T>();
+    constexpr int V = fused_width<T>();
     constexpr uint64_t W = lbm::kWave - 2 * lbm::kFusedHalo;
     const T *f = (const T *)f_;
     T *buf = (T *)buf_;
@@ -412,11 +414,17 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
     const dim3 grid((unsigned)(nstrips * nsegs)), block(lbm::kWave);
+    // fp64 lid-driven sweeps of four steps need ~270 VGPRs: capped at 256 they spill inside the row
+    // loop (84 GLUPS against 110 uncapped at 16384^2), everything else runs two wavefronts per SIMD
+    constexpr bool kWide4 = LID && sizeof(T) == 8;
     switch (k) {
         case 1: hipLaunchKernelGGL((lbm::k_fused<T, V, 1, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
         case 2: hipLaunchKernelGGL((lbm::k_fused<T, V, 2, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
         case 3: hipLaunchKernelGGL((lbm::k_fused<T, V, 3, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
-        case 4: hipLaunchKernelGGL((lbm::k_fused<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
+        case 4:
+            if (kWide4) hipLaunchKernelGGL((lbm::k_fused_wide<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
+            else        hipLaunchKernelGGL((lbm::k_fused<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
+            break;
         default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
     }
     return launch_status("fused sweep");
@@ -440,7 +448,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
                     "%d fused steps of rows [%llu,%llu) need %d ghost rows on either side inside [0,%llu)",
                     k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
     if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
-        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 16-byte vectors (nx=%llu)",
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 8-byte vectors (nx=%llu)",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -481,7 +489,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
                         (unsigned long long)need_lo, (unsigned long long)need_hi);
     }
     if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
-        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 16-byte vectors (nx=%llu)",
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 8-byte vectors (nx=%llu)",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32

@@ -5,16 +5,20 @@
 // kernels advance K = 2..4 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
 // ...) while reading every population once and writing it once:
 //
-//   * one wavefront owns a strip of 64 x 16 bytes of a row and marches it through a segment of
-//     rows; one row of 9 x 1 KiB is loaded per iteration (prefetched one iteration ahead);
+//   * one wavefront owns a strip of 64 x 8 bytes of a row and marches it through a segment of
+//     rows; one row of 9 x 512 bytes is loaded per iteration (prefetched one iteration ahead).
+//     Eight bytes per lane, not sixteen: a lone wavefront per SIMD cannot hide its own issue and
+//     memory stalls (measured 62 % VALU-active at K=4 with 16-byte lanes and 440 VGPRs); with half
+//     the nodes per lane the K=4 pull kernel fits 256 VGPRs, two wavefronts share a SIMD and the
+//     fp32 sweep gains 11 % (211 -> 234 GLUPS at 16384^2);
 //   * the time levels between the loaded and the stored one never leave the register file: per
 //     level a ring of nine vectors holds the populations that the next rows still need ((2,5,6) of
 //     two rows, (0,1,3) of one row), so iteration i relaxes row R at level 1, row R-1 at level 2,
 //     ... and stores row R-K+1 at level K;
 //   * the x neighbours that the streaming step needs come from the adjacent lanes through DPP
 //     wavefront shifts -- no LDS, no barriers, every global access a naturally aligned 16 bytes;
-//   * the dependency cone is paid for with redundant work at the strip and segment edges: two
-//     vectors (32 bytes) of x halo per side, so that the 60 stored vectors of a strip cover whole
+//   * the dependency cone is paid for with redundant work at the strip and segment edges: four
+//     lanes (32 bytes) of x halo per side, so that the 56 stored lanes of a strip cover whole
 //     64-byte lines (partially written lines cost 20 % of the achieved HBM rate), and K or K-1 rows
 //     of y halo per segment end;
 //   * arithmetic per node and time step is the one-step kernels' `collide`, in the same order, so
@@ -35,8 +39,9 @@
 
 namespace lbm {
 
-constexpr int kFusedHalo = 2;      // vectors of x halo on either side of a strip
-constexpr int kFusedMaxSteps = 4;  // K*1 node of halo per step must fit in kFusedHalo vectors (fp64: 4 nodes)
+constexpr int kFusedLaneBytes = 8;  // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node
+constexpr int kFusedHalo = 4;       // vectors (lanes) of x halo on either side of a strip
+constexpr int kFusedMaxSteps = 4;   // one node of halo per step must fit in kFusedHalo vectors (fp64: 4 nodes)
 
 struct FusedGeom {
     uint32_t nx, ny;        // row length, rows in the array
@@ -174,9 +179,10 @@ struct RowIn {
 
 // K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
 template <typename T, int V, int K, bool PUSH, bool LID>
-__global__ void __launch_bounds__(kWave)
-k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
+__device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
+                                           const T om, const T df_lid)
 {
+    static_assert(V * sizeof(T) == kFusedLaneBytes, "one lane owns kFusedLaneBytes of a row");
     constexpr int H = kFusedHalo;
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
@@ -233,17 +239,31 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
         }
     };
 
-    // iteration i relaxes row Rc = ys - D + i first
-    auto load_row = [&](RowIn<T, V> &d, uint32_t i) {
-        const int64_t Rc = (int64_t)ys - D + (int64_t)i;
-        const uint32_t y = row_index(Rc);
+    // Sliding window over the rows the next load needs, advanced incrementally (a 64-bit modulo per
+    // row index would cost more scalar instructions than the relaxation costs vector ones): Rn is
+    // the lattice row relaxed first in the iteration being loaded, y_d / y_m / y_u the array rows of
+    // Rn-1, Rn, Rn+1.  Loads are requested in iteration order.
+    int32_t Rn = (int32_t)ys - D;
+    uint32_t y_d = row_index((int64_t)Rn - 1), y_m = row_index((int64_t)Rn), y_u = row_index((int64_t)Rn + 1);
+    auto advance_rows = [&]() {
+        ++Rn;
+        y_d = y_m;
+        y_m = y_u;
+        if (g.wrap_y) {
+            y_u = (y_u + 1 == g.ny) ? 0u : y_u + 1;
+        } else {
+            const int32_t r = Rn + 1;
+            y_u = r < 0 ? 0u : (r >= (int32_t)g.ny ? g.ny - 1 : (uint32_t)r);
+        }
+    };
+    auto load_row = [&](RowIn<T, V> &d) {
+        const uint32_t y = y_m, yd = y_d, yu = y_u;
         if (PUSH) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) load_a<T, V>(d.v[q], rowp(f, plane, q, y, g.nx) + x0);
         } else {
-            const uint32_t yd = row_index(Rc - 1), yu = row_index(Rc + 1);
             bool t, b;
-            wall_rows(Rc, t, b);
+            wall_rows(Rn, t, b);
             // pull-push.cpp:13-21; at the lid / the bottom wall the node's own populations instead
             const T *p7 = t ? rowp(f, plane, 5, y, g.nx) : rowp(f, plane, 7, yu, g.nx);
             const T *p4 = t ? rowp(f, plane, 2, y, g.nx) : rowp(f, plane, 4, yu, g.nx);
@@ -270,6 +290,7 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
                 d.w[3] = rowp(f, plane, 5, y, g.nx)[x0 + V - 1];
             }
         }
+        advance_rows();
     };
 
     // per register-level streaming step: A = (2,5,6) two rows back, B = (0,1,3) one row back,
@@ -350,15 +371,33 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
     RowIn<T, V> in0, in1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { in0.w[k] = T(0); in1.w[k] = T(0); }
-    load_row(in0, 0);
+    load_row(in0);
     for (uint32_t i = 0; i < iters; i += 2) {
-        if (i + 1 < iters) load_row(in1, i + 1);
+        if (i + 1 < iters) load_row(in1);
         iteration(in0, i);
         if (i + 1 < iters) {
-            if (i + 2 < iters) load_row(in0, i + 2);
+            if (i + 2 < iters) load_row(in0);
             iteration(in1, i + 1);
         }
     }
+}
+
+// At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
+// scalar bookkeeping, memory issue and hazard stalls with vector work.  Every instantiation but the
+// fp64 lid-driven K=4 ones fits (or spills a handful of loop-invariant values).
+template <typename T, int V, int K, bool PUSH, bool LID>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
+k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
+{
+    fused_body<T, V, K, PUSH, LID>(f, buf, g, om, df_lid);
+}
+
+// The same sweep without the register cap (one wavefront per SIMD if it needs more than 256 VGPRs).
+template <typename T, int V, int K, bool PUSH, bool LID>
+__global__ void __launch_bounds__(kWave)
+k_fused_wide(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
+{
+    fused_body<T, V, K, PUSH, LID>(f, buf, g, om, df_lid);
 }
 
 }  // namespace lbm

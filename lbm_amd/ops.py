@@ -153,7 +153,7 @@ def pull_lid_rows(f, buf, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob):
 
 # ---------------------------------------------------------------- several steps per call -----
 def fused_max_steps(f) -> int:
-    """Largest `nsteps` the fused sweeps accept for this array (1: rows are not whole 16-byte vectors)."""
+    """Largest `nsteps` the fused sweeps accept for this array (1: rows are not whole 8-byte vectors)."""
     nx, _ = _check_f(f)
     return int(capi.load().lbm_fused_max_steps(_prec(f), nx))
 

@@ -179,6 +179,7 @@ class SlabSimulation:
         self.f[:, :G].zero_(); self.f[:, n + G:].zero_()
         self.buf[:, :G].zero_(); self.buf[:, n + G:].zero_()
         self.blocks = 0     # exchanges so far = launches of the interior sweep
+        self._stage = None  # deep-halo staging buffers, allocated at the first exchange
         self._max = torch.empty(2, dtype=dtype, device=self.device)
         self.t = 0
 
@@ -288,8 +289,9 @@ class SlabSimulation:
 
     def _exchange_deep(self, a: torch.Tensor) -> None:
         """Deep-halo exchange on array `a` (edge/communication stream): my G lowest and G highest
-        rows, all nine populations, become the neighbours' ghost rows.  A [G, NX] block of one
-        population is contiguous, so it is sent and received in place."""
+        rows, all nine populations, become the neighbours' ghost rows.  The nine [G, NX] blocks of
+        one edge are gathered into one contiguous staging buffer, so an exchange is two sends and
+        two receives whatever G is (every message costs the transport a fixed overhead)."""
         n, G = self.n, self.G
         lo_own, hi_own = slice(G, 2 * G), slice(n, n + G)          # rows I send down / up
         lo_ghost, hi_ghost = slice(0, G), slice(n + G, n + 2 * G)   # rows I receive from below / above
@@ -300,25 +302,30 @@ class SlabSimulation:
                     a[:, hi_ghost].copy_(a[:, lo_own])
                     a[:, lo_ghost].copy_(a[:, hi_own])
             else:
+                if self._stage is None:
+                    self._stage = torch.empty((4, 9, G, self.nx), dtype=a.dtype, device=a.device)
+                send_lo, send_hi, recv_lo, recv_hi = self._stage
                 # same pairing rule as _exchange: sends [down, up], receives [from above, from below]
                 p2p: List[dist.P2POp] = []
                 if self.lower is not None:
-                    for q in range(9):
-                        p2p.append(dist.P2POp(dist.isend, a[q, lo_own], self._peer(self.lower), self.group, tag=q))
+                    send_lo.copy_(a[:, lo_own])
+                    p2p.append(dist.P2POp(dist.isend, send_lo, self._peer(self.lower), self.group))
                 if self.upper is not None:
-                    for q in range(9):
-                        p2p.append(dist.P2POp(dist.isend, a[q, hi_own], self._peer(self.upper), self.group, tag=q))
+                    send_hi.copy_(a[:, hi_own])
+                    p2p.append(dist.P2POp(dist.isend, send_hi, self._peer(self.upper), self.group))
                 if self.upper is not None:
-                    for q in range(9):
-                        p2p.append(dist.P2POp(dist.irecv, a[q, hi_ghost], self._peer(self.upper), self.group, tag=q))
+                    p2p.append(dist.P2POp(dist.irecv, recv_hi, self._peer(self.upper), self.group))
                 if self.lower is not None:
-                    for q in range(9):
-                        p2p.append(dist.P2POp(dist.irecv, a[q, lo_ghost], self._peer(self.lower), self.group, tag=q))
+                    p2p.append(dist.P2POp(dist.irecv, recv_lo, self._peer(self.lower), self.group))
                 if p2p:
                     if not self.stream_ordered:
                         (self.comm_stream if self.overlap else self.compute_stream).synchronize()
                     for req in dist.batch_isend_irecv(p2p):
                         req.wait()
+                if self.upper is not None:
+                    a[:, hi_ghost].copy_(recv_hi)
+                if self.lower is not None:
+                    a[:, lo_ghost].copy_(recv_lo)
             if self.cuda and self.overlap:
                 self._halo_done.record(self.comm_stream)
         self._halo_pending = True

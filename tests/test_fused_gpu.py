@@ -44,10 +44,11 @@ def run_fused(scene, scheme, d_f, d_b, om, y_lo, y_hi, k, wrap_y=True, y_goff=0,
         getattr(ops, f"{scheme}_lid_fused")(d_f, d_b, om, RHO, U, y_lo, y_hi, y_goff, ny_glob, k)
 
 
-# row lengths: one strip, a partial last strip, several strips (a strip stores 60 vectors = 240
-# fp32 / 120 fp64 nodes), the shortest supported rows; heights: fewer rows than steps (multiple
-# wraps), one segment, several segments
-SIZES = [(8, 3), (8, 1), (64, 48), (240, 9), (244, 7), (1024, 70), (2048, 5), (4, 6), (724, 33)]
+# row lengths: one strip, a partial last strip, several strips (a strip stores 56 lanes = 112 fp32 /
+# 56 fp64 nodes), the shortest supported rows, odd lengths (fp64 only); heights: fewer rows than
+# steps (multiple wraps), one segment, several segments
+SIZES = [(8, 3), (8, 1), (64, 48), (112, 9), (114, 7), (1024, 70), (2048, 5), (4, 6), (724, 33), (2, 5), (57, 6),
+         (229, 11)]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -65,7 +66,7 @@ def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
         d_f = torch.from_numpy(f).cuda()
         d_b = torch.full_like(d_f, float("nan"))
         if ops.fused_max_steps(d_f) == 1:
-            continue   # rows shorter than two 16-byte vectors
+            continue   # rows shorter than two 8-byte vectors
         run_fused(scene, scheme, d_f, d_b, om, 0, ny, k, wrap_y=True, y_goff=0, ny_glob=ny)
         assert_bits_equal(d_b.cpu().numpy(), want, f"{scene}/{scheme} fused k={k} {nx}x{ny}")
         assert torch.equal(d_f.cpu(), torch.from_numpy(f)), "the input array was modified"
@@ -122,7 +123,9 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
     orc.pull_periodic_no_mpi(f, want, np.float32(0.7))
     assert_bits_equal(d_b.cpu().numpy(), want, "nsteps=1")
     assert ops.fused_max_steps(d_f) == 4
-    odd = torch.zeros((9, 4, 66), dtype=torch.float64, device="cuda")
+    odd = torch.zeros((9, 4, 67), dtype=torch.float64, device="cuda")
+    assert ops.fused_max_steps(odd) == 4      # one fp64 node per lane: any row length
+    odd = torch.zeros((9, 4, 66), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(odd) == 4
     odd = torch.zeros((9, 4, 67), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(odd) == 1
