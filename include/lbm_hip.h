@@ -140,9 +140,9 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
 int lbm_fused_max_steps(int prec, uint64_t nx);
 
 /* How many of the `remaining` iterations of the time loop the next call should take for a lattice
- * of `rows` rows of nx nodes: lbm_fused_max_steps() for lattices that stream from HBM, 1 for
- * lattices small enough to stay in the on-die caches or not supported by the fused sweeps, never
- * more than `remaining`.  The time loops of this library's drivers (main.cpp:64-83) ask this before
+ * of `rows` rows of nx nodes: lbm_fused_max_steps() (1 for row lengths the fused sweeps do not
+ * support), never more than `remaining`.  Environment: LBM_FUSED_MAX_STEPS caps the answer,
+ * LBM_FUSED_MIN_NODES makes lattices below that many nodes take one step per launch.  The time loops of this library's drivers (main.cpp:64-83) ask this before
  * every launch. */
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining);
 

@@ -387,19 +387,11 @@ bool fused_supported(uint64_t nx)
     return nx % V == 0 && nx >= 2 * V;
 }
 
-template <typename T, bool PUSH, bool LID>
-int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_, double u_,
-                uint64_t y_lo, uint64_t y_hi, int wrap_y, int64_t y_goff, uint64_t ny_glob, int k,
-                hipStream_t stream)
+template <typename T, int V, bool PUSH, bool LID, bool WIDE>
+int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
+                 int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
-    if (y_lo == y_hi) return LBM_OK;
-    constexpr int V = fused_width<T>();
-    constexpr uint64_t W = lbm::kWave - 2 * lbm::kFusedHalo;
-    const T *f = (const T *)f_;
-    T *buf = (T *)buf_;
-    const T om = (T)om_;
-    const T rho = (T)rho_, u = (T)u_;
-    const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
+    constexpr uint64_t W = lbm::kWave - 2 * lbm::fused_halo_lanes<T, V>();
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
     uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 64);
@@ -414,20 +406,47 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
     const dim3 grid((unsigned)(nstrips * nsegs)), block(lbm::kWave);
-    // fp64 lid-driven sweeps of four steps need ~270 VGPRs: capped at 256 they spill inside the row
-    // loop (84 GLUPS against 110 uncapped at 16384^2), everything else runs two wavefronts per SIMD
-    constexpr bool kWide4 = LID && sizeof(T) == 8;
+#define LBM_FUSED_CASE(KK)                                                                                       \
+    case KK:                                                                                                     \
+        if constexpr (WIDE) hipLaunchKernelGGL((lbm::k_fused_wide<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); \
+        else                hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);      \
+        break;
     switch (k) {
-        case 1: hipLaunchKernelGGL((lbm::k_fused<T, V, 1, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
-        case 2: hipLaunchKernelGGL((lbm::k_fused<T, V, 2, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
-        case 3: hipLaunchKernelGGL((lbm::k_fused<T, V, 3, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); break;
-        case 4:
-            if (kWide4) hipLaunchKernelGGL((lbm::k_fused_wide<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
-            else        hipLaunchKernelGGL((lbm::k_fused<T, V, 4, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
-            break;
+        LBM_FUSED_CASE(1)
+        LBM_FUSED_CASE(2)
+        LBM_FUSED_CASE(3)
+        LBM_FUSED_CASE(4)
         default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
     }
+#undef LBM_FUSED_CASE
     return launch_status("fused sweep");
+}
+
+template <typename T, bool PUSH, bool LID>
+int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_, double u_,
+                uint64_t y_lo, uint64_t y_hi, int wrap_y, int64_t y_goff, uint64_t ny_glob, int k,
+                hipStream_t stream)
+{
+    if (y_lo == y_hi) return LBM_OK;
+    const T *f = (const T *)f_;
+    T *buf = (T *)buf_;
+    const T om = (T)om_;
+    const T rho = (T)rho_, u = (T)u_;
+    const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
+    // Eight bytes of a row per lane and two wavefronts per SIMD everywhere, except the fp64
+    // lid-driven sweeps of four steps: they need ~270 VGPRs at 8 bytes per lane (capped at 256 they
+    // spill inside the row loop: 84 GLUPS at 16384^2, uncapped 99) and run fastest with 16 bytes
+    // per lane and one wavefront per SIMD (111-114 GLUPS) when the row length allows it.
+    constexpr int V8 = fused_width<T>();
+    if constexpr (LID && sizeof(T) == 8) {
+        if (k == 4) {
+            constexpr int V16 = lbm::kFusedWideLaneBytes / (int)sizeof(T);
+            if (nx % V16 == 0 && nx >= 2 * V16)
+                return launch_fused<T, V16, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+            return launch_fused<T, V8, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+        }
+    }
+    return launch_fused<T, V8, PUSH, LID, false>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
 }
 
 template <bool PULL>
@@ -755,11 +774,12 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     if (remaining == 0) return 0;
     const int kmax = lbm_fused_max_steps(prec, nx);
     if (kmax <= 1) return kmax;   // 0: bad precision, 1: one-step sweeps only
-    // Lattices that live in the on-die caches gain nothing from fewer passes over memory, and too
-    // few strips x segments leave the chip idle (1024^2 fp32: 65 GLUPS fused against 66 one-step;
-    // 4096^2: 168 against 88).
+    // Measured on MI355X (fp32 pull, square lattices, one step per launch -> four): 512^2 23 -> 38
+    // GLUPS, 1024^2 65 -> 95, 2048^2 68 -> 137, 4096^2 86 -> 180, 8192^2 77 -> 231, 16384^2 85 -> 242:
+    // fusing pays at every size (small lattices are launch-bound, large ones HBM-bound), so there is
+    // no size threshold by default; LBM_FUSED_MIN_NODES sets one.
     const char *e = getenv("LBM_FUSED_MIN_NODES");
-    const uint64_t min_nodes = e ? strtoull(e, nullptr, 10) : (3ull << 20);
+    const uint64_t min_nodes = e ? strtoull(e, nullptr, 10) : 0ull;
     if (nx * rows < min_nodes) return 1;
     const char *m = getenv("LBM_FUSED_MAX_STEPS");
     uint64_t k = m ? strtoull(m, nullptr, 10) : (uint64_t)kmax;

@@ -39,9 +39,11 @@
 
 namespace lbm {
 
-constexpr int kFusedLaneBytes = 8;  // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node
-constexpr int kFusedHalo = 4;       // vectors (lanes) of x halo on either side of a strip
-constexpr int kFusedMaxSteps = 4;   // one node of halo per step must fit in kFusedHalo vectors (fp64: 4 nodes)
+constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node ...
+constexpr int kFusedWideLaneBytes = 16;  // ... or 16 bytes in the instantiations that run one wavefront per SIMD
+constexpr int kFusedHaloBytes = 32;  // x halo on either side of a strip: stored lanes then cover whole 64-byte lines
+constexpr int kFusedMaxSteps = 4;    // one node of halo per step must fit in the halo (fp64: 4 nodes)
+template <typename T, int V> constexpr int fused_halo_lanes() { return kFusedHaloBytes / (V * (int)sizeof(T)); }
 
 struct FusedGeom {
     uint32_t nx, ny;        // row length, rows in the array
@@ -182,8 +184,8 @@ template <typename T, int V, int K, bool PUSH, bool LID>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
-    static_assert(V * sizeof(T) == kFusedLaneBytes, "one lane owns kFusedLaneBytes of a row");
-    constexpr int H = kFusedHalo;
+    static_assert(V * sizeof(T) == 8 || V * sizeof(T) == 16, "a lane owns 8 or 16 bytes of a row");
+    constexpr int H = fused_halo_lanes<T, V>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
     constexpr int NG = PUSH ? K : K - 1;     // streaming steps done in registers

@@ -46,14 +46,17 @@ CASES = [("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")]
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scene,scheme", CASES)
 @pytest.mark.parametrize("nx,ny", SIZES)
-def test_populations_match_oracle_bit_for_bit(dtype, scene, scheme, nx, ny):
+@pytest.mark.parametrize("max_fuse", [1, None], ids=["one-step", "fused"])
+def test_populations_match_oracle_bit_for_bit(dtype, scene, scheme, nx, ny, max_fuse):
+    """max_fuse=1: one launch of the one-step sweep per time step; None: the time loop's default
+    (runs of up to four steps per fused launch where the row length allows it)."""
     for omega in (0.5, 1.0, 1.7):
         sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
         ref, _ = orc.run(scene, scheme, nx, ny, 0, omega, dtype)
         assert_bits_equal(sim.f.cpu().numpy(), ref, f"init {scene} {nx}x{ny}")
         done = 0
         for upto in (1, 2, 10, 60):
-            sim.step(upto - done)
+            sim.step(upto - done, max_fuse=max_fuse)
             done = upto
             ref, _ = orc.run(scene, scheme, nx, ny, upto, omega, dtype)
             assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} {nx}x{ny} w={omega} t={upto}")
@@ -66,12 +69,15 @@ def test_long_run_1000_steps(dtype, scene, scheme, monkeypatch):
     ref, _ = orc.run(scene, scheme, nx, ny, 1000, omega, dtype)
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
-    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps")
-    # the same run with the time loop told to fuse steps even on this small lattice
-    monkeypatch.setenv("LBM_FUSED_MIN_NODES", "0")
+    assert sim.launches == 250
+    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 4")
+    # the same run with a size threshold that sends this lattice to the one-step sweeps
+    monkeypatch.setenv("LBM_FUSED_MIN_NODES", "1000000")
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
-    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches")
+    assert sim.launches == 1000
+    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, one-step launches")
+    monkeypatch.delenv("LBM_FUSED_MIN_NODES")
     monkeypatch.setenv("LBM_FUSED_MAX_STEPS", "3")
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
