@@ -377,6 +377,12 @@ unsigned fused_seg_rows_default()
     return e ? (unsigned)atoi(e) : 0u;
 }
 unsigned g_fused_seg_rows = fused_seg_rows_default();
+int fused_xcd_default()
+{
+    const char *e = getenv("LBM_FUSED_XCD");
+    return e ? atoi(e) : 0;
+}
+int g_fused_xcd = fused_xcd_default();
 
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
 
@@ -405,7 +411,9 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     g.nx = (uint32_t)nx; g.ny = (uint32_t)ny; g.y_lo = (uint32_t)y_lo; g.y_hi = (uint32_t)y_hi;
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
-    const dim3 grid((unsigned)(nstrips * nsegs)), block(lbm::kWave);
+    g.xcd_map = g_fused_xcd;
+    const uint64_t nsegs_grid = g.xcd_map ? (nsegs + 7) / 8 * 8 : nsegs;
+    const dim3 grid((unsigned)(nstrips * nsegs_grid)), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
         if constexpr (WIDE) hipLaunchKernelGGL((lbm::k_fused_wide<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); \

@@ -51,6 +51,7 @@ struct FusedGeom {
     int wrap_y;             // rows outside [0,ny) wrap around (whole periodic lattice on this device)
     uint32_t seg_rows;      // rows stored per wavefront
     uint32_t nstrips, nsegs;
+    int xcd_map;            // != 0: deal whole segments to the XCDs (see fused_body)
     int64_t y_goff;         // lid scenes: global row = row + y_goff
     uint64_t ny_glob;       //             cavity height
 };
@@ -192,8 +193,18 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     constexpr int D = PUSH ? K : K - 1;      // rows between a segment's first row and the first row relaxed
     constexpr int NR = NG > 0 ? NG : 1;
 
-    const uint32_t strip = blockIdx.x % g.nstrips;
-    const uint32_t seg = blockIdx.x / g.nstrips;
+    // Workgroups go to the 8 XCDs round-robin.  Plain mapping: strip fastest, so the two neighbours
+    // of a strip (which share its halo lines) run on other XCDs.  xcd_map: XCD j takes segments
+    // j, j+8, ... and walks all strips of a segment in order, so halo lines are shared in one L2.
+    uint32_t strip, seg;
+    if (g.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        seg = (slot / g.nstrips) * 8 + xcd;
+        strip = slot % g.nstrips;
+    } else {
+        strip = blockIdx.x % g.nstrips;
+        seg = blockIdx.x / g.nstrips;
+    }
     if (seg >= g.nsegs) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t nxv = g.nx / V;
