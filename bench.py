@@ -156,12 +156,6 @@ def main():
     nx, ny_loc = args.nx, args.ny_per_gpu
     ny_glob = ny_loc * world
 
-    # LBM_BENCH_STREAMS=k: run on the k-th freshly created (non-default) stream, to see which hardware
-    # queue the sweeps share with the RCCL stream
-    nstreams = int(os.environ.get("LBM_BENCH_STREAMS", "0"))
-    if nstreams:
-        pool = [torch.cuda.Stream(device) for _ in range(nstreams)]
-        torch.cuda.set_stream(pool[-1])
     if world == 1 and args.slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
