@@ -124,28 +124,32 @@ __device__ __forceinline__ void store_to_left(T *row, uint32_t x0, uint32_t nx, 
 // (push), :454-483 (lid): rho summed left to right, one division, shared sub-expressions
 // f45*s*s = (f45*s)*s, bracket ((1 -+ 3a) + a2) - usq, out = f + om*((w*bracket) - f).
 // Constants are rounded once from double (pull-push.cpp:39-43).
-template <typename T>
-__device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, const T f_3,
-                                        const T f_4, const T f_5, const T f_6, const T f_7,
-                                        const T f_8, const T om, T (&o)[9])
+// X is the arithmetic type of one "lane group": T itself, or a short vector of T whose elements are
+// independent nodes (elementwise IEEE operations, so every node sees exactly the scalar expression
+// tree).  With X = float x 2 the adds, subtracts and multiplies become packed v_pk_* instructions.
+template <typename X, typename T>
+__device__ __forceinline__ void collide_x(const X f_0, const X f_1, const X f_2, const X f_3,
+                                          const X f_4, const X f_5, const X f_6, const X f_7,
+                                          const X f_8, const T om_, X (&o)[9])
 {
-    const T rho = f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8;
-    const T rho_inv = T(1.0) / rho;
-    const T ux = (f_1 - f_3 + f_5 - f_6 - f_7 + f_8) * rho_inv;
-    const T uy = (f_2 - f_4 + f_5 + f_6 - f_7 - f_8) * rho_inv;
-    const T f45 = T(4.5), f15 = T(1.5);
-    const T f49 = T(4. / 9.), f19 = T(1. / 9.), f136 = T(1. / 36.);
-    const T one = T(1), three = T(3);
-    const T w_1_36 = rho * f136;
-    const T w_1_9 = rho * f19;
-    const T w_4_9 = rho * f49;
-    const T uxpuy = ux + uy;
-    const T uxpuy_2 = f45 * uxpuy * uxpuy;
-    const T uymux = uy - ux;
-    const T uymux_2 = f45 * uymux * uymux;
-    const T ux_2 = f45 * ux * ux;
-    const T uy_2 = f45 * uy * uy;
-    const T usq = f15 * (ux * ux + uy * uy);
+    const X om = X(om_);
+    const X rho = f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8;
+    const X rho_inv = X(T(1.0)) / rho;
+    const X ux = (f_1 - f_3 + f_5 - f_6 - f_7 + f_8) * rho_inv;
+    const X uy = (f_2 - f_4 + f_5 + f_6 - f_7 - f_8) * rho_inv;
+    const X f45 = X(T(4.5)), f15 = X(T(1.5));
+    const X f49 = X(T(4. / 9.)), f19 = X(T(1. / 9.)), f136 = X(T(1. / 36.));
+    const X one = X(T(1)), three = X(T(3));
+    const X w_1_36 = rho * f136;
+    const X w_1_9 = rho * f19;
+    const X w_4_9 = rho * f49;
+    const X uxpuy = ux + uy;
+    const X uxpuy_2 = f45 * uxpuy * uxpuy;
+    const X uymux = uy - ux;
+    const X uymux_2 = f45 * uymux * uymux;
+    const X ux_2 = f45 * ux * ux;
+    const X uy_2 = f45 * uy * uy;
+    const X usq = f15 * (ux * ux + uy * uy);
     o[7] = f_7 + om * ((w_1_36 * (one - three * uxpuy + uxpuy_2 - usq)) - f_7);
     o[4] = f_4 + om * ((w_1_9 * (one - three * uy + uy_2 - usq)) - f_4);
     o[8] = f_8 + om * ((w_1_36 * (one - three * uymux + uymux_2 - usq)) - f_8);
@@ -155,6 +159,41 @@ __device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, c
     o[6] = f_6 + om * ((w_1_36 * (one + three * uymux + uymux_2 - usq)) - f_6);
     o[2] = f_2 + om * ((w_1_9 * (one + three * uy + uy_2 - usq)) - f_2);
     o[5] = f_5 + om * ((w_1_36 * (one + three * uxpuy + uxpuy_2 - usq)) - f_5);
+}
+
+template <typename T>
+__device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, const T f_3,
+                                        const T f_4, const T f_5, const T f_6, const T f_7,
+                                        const T f_8, const T om, T (&o)[9])
+{
+    collide_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+}
+
+// Relax the V nodes of one lane: c[q][i] -> o[q][i].  fp32 nodes go through the arithmetic in
+// pairs (packed instructions), everything else one by one.
+template <typename T, int V, bool PAIRS = true>
+__device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], const T om)
+{
+    if constexpr (PAIRS && sizeof(T) == 4 && V % 2 == 0) {
+        typedef T pair_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < V; i += 2) {
+            pair_t in[9], r[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { in[q].x = c[q][i]; in[q].y = c[q][i + 1]; }
+            collide_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { o[q][i] = r[q].x; o[q][i + 1] = r[q].y; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            T r[9];
+            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[q][i] = r[q];
+        }
+    }
 }
 
 // Macroscopic velocity of one node as io.cpp:143-171 and io.cpp:190-202 form it (the two sites
