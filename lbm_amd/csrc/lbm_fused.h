@@ -193,6 +193,8 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // Workgroups go to the 8 XCDs round-robin.  Plain mapping: strip fastest, so the two neighbours
     // of a strip (which share its halo lines) run on other XCDs.  xcd_map: XCD j takes segments
     // j, j+8, ... and walks all strips of a segment in order, so halo lines are shared in one L2.
+    // Measured at 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every
+    // segment's strips instead): address-order dispatch is worth more than the shared lines.
     uint32_t strip, seg;
     if (g.xcd_map) {
         const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
