@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--scene", choices=["shear", "lid"], default="shear")
     ap.add_argument("--nx", type=int, default=16384)
     ap.add_argument("--ny-per-gpu", type=int, default=16384)
+    ap.add_argument("--ny-global", type=int, default=0,
+                    help="strong scaling: fixed global height split over the ranks (overrides --ny-per-gpu), "
+                         "e.g. --nx 32768 --ny-global 32768")
     ap.add_argument("--omega", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="rows of the CPU-baseline sample")
@@ -155,6 +158,10 @@ def main():
     bytes_per_node = 72 if args.precision == "fp32" else 144
     nx, ny_loc = args.nx, args.ny_per_gpu
     ny_glob = ny_loc * world
+    strong = args.ny_global > 0
+    if strong:
+        ny_glob = args.ny_global
+        ny_loc = -(-ny_glob // world)   # the largest slab (remainder rows go to the lowest ranks)
 
     if world == 1 and args.slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -224,7 +231,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL over gloo on shared GPUs: not a measurement)",

@@ -401,8 +401,23 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
     uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 64);
-    if (!g_fused_seg_rows)
-        while (seg > 8 && nstrips * ((rows + seg - 1) / seg) < 4096) seg /= 2;
+    if (!g_fused_seg_rows) {
+        // A wavefront walks seg + (rows of y halo) iterations one after the other, and the chip holds
+        // `slots` wavefronts at a time.  Grids of many rounds use the measured segment length; smaller
+        // ones pick the length that minimises rounds x iterations -- the tail round of a 2.4-round grid
+        // is as expensive as a full one (fp32 pull, GLUPS before -> after: 512^2 38 -> 46, 2048^2
+        // 137 -> 174, 4096^2 180 -> 224, 8192^2 231 -> 253; 1024^2 stays at 107, launch-gap-bound).
+        const uint64_t slots = (WIDE ? 1024 : 2048);
+        const uint64_t extra = PUSH ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
+        if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
+            uint64_t best = ~0ull;
+            for (uint64_t s = 64; s >= 2; --s) {
+                const uint64_t waves = nstrips * ((rows + s - 1) / s);
+                const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
+                if (cost < best) { best = cost; seg = s; }
+            }
+        }
+    }
     if (seg > rows) seg = rows;
     const uint64_t nsegs = (rows + seg - 1) / seg;
     if (nstrips * nsegs > 0x7fffffffull)
