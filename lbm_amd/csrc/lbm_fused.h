@@ -380,16 +380,27 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         }
     };
 
-    RowIn<T, V> in0, in1;
+    // Rows are requested PF iterations ahead of their use; PF + 1 register buffers rotate through
+    // a loop unrolled by PF + 1.  One iteration of fp64 work (~0.8 us) is shorter than the memory
+    // latency under load, so fp64 looks two rows ahead (37 % of its wave time sat in s_waitcnt with
+    // one); fp32 has no registers to spare for that under the 256-register cap.
+    constexpr int PF = (sizeof(T) == 8 && V == 1) ? 2 : 1;
+    RowIn<T, V> in[PF + 1];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { in0.w[k] = T(0); in1.w[k] = T(0); }
-    load_row(in0);
-    for (uint32_t i = 0; i < iters; i += 2) {
-        if (i + 1 < iters) load_row(in1);
-        iteration(in0, i);
-        if (i + 1 < iters) {
-            if (i + 2 < iters) load_row(in0);
-            iteration(in1, i + 1);
+    for (int j = 0; j <= PF; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[j].w[k] = T(0);
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if ((uint32_t)j < iters) load_row(in[j]);
+    for (uint32_t i0 = 0; i0 < iters; i0 += PF + 1) {
+#pragma unroll
+        for (int j = 0; j <= PF; ++j) {
+            const uint32_t i = i0 + j;
+            if (i < iters) {
+                if (i + PF < iters) load_row(in[(j + PF) % (PF + 1)]);
+                iteration(in[j], i);
+            }
         }
     }
 }
