@@ -23,6 +23,9 @@
 //     of y halo per segment end;
 //   * arithmetic per node and time step is the one-step kernels' `collide`, in the same order, so
 //     the result is bit-identical to K one-step sweeps.
+// Tried and rejected: strips shared by 2 or 4 wavefronts (boundary scalars through LDS, one barrier
+// per streaming step) halve or quarter the x halo and the over-fetched lines, but the barriers cost
+// more than that saves (fp32 K=4: 245 -> 227 / 222 GLUPS, fp64 131 -> 115 / 112).
 //
 // Pull scheme (stored state: post-collision populations):  [gather from memory, relax] then K-1 x
 // [gather from registers, relax], store.   Push scheme (stored state: post-streaming populations):
