@@ -368,9 +368,9 @@ int lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doubl
 // ---- several time steps per pass (lbm_fused.h) ------------------------------------------------
 // Rows stored per wavefront.  Measured on MI355X: long segments amortise the K-1 (pull) or K (push)
 // rows of redundant work at either end, short ones keep more wavefronts in flight; at 16384^2 fp32
-// the best are 16 rows for K=2 (147 GLUPS), 32 for K=3 (193), 64 for K=4 (217), and a 4096^2 lattice
-// wants 16 rows even for K=4 (168 GLUPS against 132 with 64): keep at least ~4 waves per SIMD lane
-// group of the chip in the grid before growing the segment.
+// (16-byte lanes) the best were 16 rows for K=2 (147 GLUPS), 32 for K=3 (193), 64 for K=4 (217); with
+// 8-byte lanes K=4 is flat from 64 to 128 rows (+1 % at 128) and loses 4 % at 256.  Small grids choose
+// by a model of rounds x iterations (launch_fused).
 unsigned fused_seg_rows_default()
 {
     const char *e = getenv("LBM_FUSED_SEG_ROWS");
@@ -400,7 +400,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     constexpr uint64_t W = lbm::kWave - 2 * lbm::fused_halo_lanes<T, V>();
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
-    uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 64);
+    uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 128);
     if (!g_fused_seg_rows) {
         // A wavefront walks seg + (rows of y halo) iterations one after the other, and the chip holds
         // `slots` wavefronts at a time.  Grids of many rounds use the measured segment length; smaller
@@ -411,7 +411,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         const uint64_t extra = PUSH ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             uint64_t best = ~0ull;
-            for (uint64_t s = 64; s >= 2; --s) {
+            for (uint64_t s = 128; s >= 2; --s) {
                 const uint64_t waves = nstrips * ((rows + s - 1) / s);
                 const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
                 if (cost < best) { best = cost; seg = s; }
