@@ -384,6 +384,9 @@ int fused_xcd_default()
 }
 int g_fused_xcd = fused_xcd_default();
 
+// the x halo of a strip (32 bytes) holds 8 fp32 or 4 fp64 nodes, one per fused step
+int max_fused_steps(int prec) { return prec == LBM_F32 ? lbm::kFusedMaxStepsF32 : lbm::kFusedMaxSteps; }
+
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
 
 template <typename T>
@@ -393,7 +396,7 @@ bool fused_supported(uint64_t nx)
     return nx % V == 0 && nx >= 2 * V;
 }
 
-template <typename T, int V, bool PUSH, bool LID, bool WIDE>
+template <typename T, int V, bool PUSH, bool LID>
 int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
@@ -407,7 +410,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         // ones pick the length that minimises rounds x iterations -- the tail round of a 2.4-round grid
         // is as expensive as a full one (fp32 pull, GLUPS before -> after: 512^2 38 -> 46, 2048^2
         // 137 -> 174, 4096^2 180 -> 224, 8192^2 231 -> 253; 1024^2 stays at 107, launch-gap-bound).
-        const uint64_t slots = (WIDE ? 1024 : 2048);
+        const uint64_t slots = 2048;   // 256 CUs x 4 SIMDs x 2 wavefronts
         const uint64_t extra = PUSH ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             uint64_t best = ~0ull;
@@ -431,15 +434,21 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const dim3 grid((unsigned)(nstrips * nsegs_grid)), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
-        if constexpr (WIDE) hipLaunchKernelGGL((lbm::k_fused_wide<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); \
-        else                hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);      \
+        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); \
         break;
     switch (k) {
         LBM_FUSED_CASE(1)
         LBM_FUSED_CASE(2)
         LBM_FUSED_CASE(3)
         LBM_FUSED_CASE(4)
-        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+        case 5: case 6:
+            if constexpr (sizeof(T) == 4) {
+                if (k == 5) hipLaunchKernelGGL((lbm::k_fused<T, V, 5, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
+                else        hipLaunchKernelGGL((lbm::k_fused<T, V, 6, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
+                break;
+            }
+            return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d is available in fp32 only", k);
+        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxStepsF32);
     }
 #undef LBM_FUSED_CASE
     return launch_status("fused sweep");
@@ -456,28 +465,16 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const T om = (T)om_;
     const T rho = (T)rho_, u = (T)u_;
     const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
-    // Eight bytes of a row per lane and two wavefronts per SIMD everywhere, except the fp64
-    // lid-driven sweeps of four steps: they need ~270 VGPRs at 8 bytes per lane (capped at 256 they
-    // spill inside the row loop: 84 GLUPS at 16384^2, uncapped 99) and run fastest with 16 bytes
-    // per lane and one wavefront per SIMD (111-114 GLUPS) when the row length allows it.
-    constexpr int V8 = fused_width<T>();
-    if constexpr (LID && sizeof(T) == 8) {
-        if (k == 4) {
-            constexpr int V16 = lbm::kFusedWideLaneBytes / (int)sizeof(T);
-            if (nx % V16 == 0 && nx >= 2 * V16)
-                return launch_fused<T, V16, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
-            return launch_fused<T, V8, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
-        }
-    }
-    return launch_fused<T, V8, PUSH, LID, false>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+    constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
+    return launch_fused<T, V8, PUSH, LID>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
 }
 
 template <bool PULL>
 int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
                    uint64_t y_lo, uint64_t y_hi, int wrap_y, int k, void *stream)
 {
-    if (k < 1 || k > lbm::kFusedMaxSteps)
-        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+    if (k < 1 || k > max_fused_steps(prec))
+        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, max_fused_steps(prec));
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
     const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
@@ -503,8 +500,8 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
               double u_lid, uint64_t y_lo, uint64_t y_hi, int64_t y_goff, uint64_t ny_glob, int k,
               void *stream)
 {
-    if (k < 1 || k > lbm::kFusedMaxSteps)
-        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+    if (k < 1 || k > max_fused_steps(prec))
+        return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, max_fused_steps(prec));
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
     {
         const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
@@ -790,7 +787,7 @@ int lbm_fused_max_steps(int prec, uint64_t nx)
 {
     if (prec != LBM_F32 && prec != LBM_F64) return 0;
     const bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
-    return ok ? lbm::kFusedMaxSteps : 1;
+    return ok ? max_fused_steps(prec) : 1;
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
 {

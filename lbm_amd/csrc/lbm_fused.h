@@ -40,12 +40,20 @@
 
 #pragma clang fp contract(off)
 
+// Streaming steps whose rings stay in registers (the rest live in LDS); tuning harnesses override.
+#ifndef LBM_FUSED_REG_RINGS_PULL
+#define LBM_FUSED_REG_RINGS_PULL 2
+#endif
+#ifndef LBM_FUSED_REG_RINGS_PUSH
+#define LBM_FUSED_REG_RINGS_PUSH 2
+#endif
+
 namespace lbm {
 
-constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node ...
-constexpr int kFusedWideLaneBytes = 16;  // ... or 16 bytes in the instantiations that run one wavefront per SIMD
+constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node
 constexpr int kFusedHaloBytes = 32;  // x halo on either side of a strip: stored lanes then cover whole 64-byte lines
 constexpr int kFusedMaxSteps = 4;    // one node of halo per step must fit in the halo (fp64: 4 nodes)
+constexpr int kFusedMaxStepsF32 = 6; // fp32 halos hold 8 nodes; beyond four steps the early rings move to LDS
 template <typename T, int V> constexpr int fused_halo_lanes() { return kFusedHaloBytes / (V * (int)sizeof(T)); }
 
 struct FusedGeom {
@@ -185,7 +193,7 @@ template <typename T, int V, int K, bool PUSH, bool LID>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
-    static_assert(V * sizeof(T) == 8 || V * sizeof(T) == 16, "a lane owns 8 or 16 bytes of a row");
+    static_assert(V * sizeof(T) == kFusedLaneBytes, "a lane owns kFusedLaneBytes of a row");
     constexpr int H = fused_halo_lanes<T, V>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
@@ -308,17 +316,39 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         advance_rows();
     };
 
-    // per register-level streaming step: A = (2,5,6) two rows back, B = (0,1,3) one row back,
-    // C = (2,5,6) one row back, w7/w8 = populations 7 / 8 one row back at the wall nodes
-    T ringA[NR][3][V], ringB[NR][3][V], ringC[NR][3][V], ring7[NR], ring8[NR];
+    // Per in-flight streaming step ("ring"): A = (2,5,6) two rows back, B = (0,1,3) one row back,
+    // C = (2,5,6) one row back, w7/w8 = populations 7 / 8 one row back at the wall nodes.  The last
+    // kRegRings rings live in registers; earlier ones live in this wavefront's own LDS (4.5 KiB per
+    // ring, no barriers), where A and C are two sets that swap roles with the parity of the
+    // iteration instead of being copied.  Measured at 16384^2 fp32: with two register rings K=4 runs
+    // as fast as with all rings in registers and K=5/6 become possible (K=6: +12 %); with three
+    // register rings the pull kernels of K>=5 spill.
+    constexpr int kRegRings = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
+    constexpr int NLDS = NG > kRegRings ? NG - kRegRings : 0;
+    constexpr int NREG = NG - NLDS > 0 ? NG - NLDS : 1;
+    typedef typename VecTypes<T, V>::vec_t ring_vec_t;
+    __shared__ ring_vec_t ring_lds[NLDS > 0 ? NLDS : 1][9][kWave];   // [ring][set*3 + k | 6 + k][lane]
+    T ringA[NREG][3][V], ringB[NREG][3][V], ringC[NREG][3][V], ring7[NR], ring8[NR];
 #pragma unroll
-    for (int s = 0; s < NR; ++s) {
+    for (int s = 0; s < NREG; ++s) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int e = 0; e < V; ++e) { ringA[s][k][e] = T(1); ringB[s][k][e] = T(1); ringC[s][k][e] = T(1); }
-        ring7[s] = T(1); ring8[s] = T(1);
     }
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { ring7[s] = T(1); ring8[s] = T(1); }
+    auto lds_get = [&](T (&d)[V], int ring, uint32_t slot) {
+        const ring_vec_t v = ring_lds[ring][slot][threadIdx.x];
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = v[e];
+    };
+    auto lds_put = [&](int ring, uint32_t slot, const T (&d)[V]) {
+        ring_vec_t v;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = d[e];
+        ring_lds[ring][slot][threadIdx.x] = v;
+    };
 
     auto iteration = [&](const RowIn<T, V> &in, uint32_t i) {
         const int64_t Rc = (int64_t)ys - D + (int64_t)i;
@@ -347,23 +377,46 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
             for (int e = 0; e < V; ++e) { F[0][e] = o[4][e]; F[1][e] = o[7][e]; F[2][e] = o[8][e]; }
             WallFlags fl = fl0;
             wall_rows(r - 1, fl.t, fl.b);
-            gather_row<T, V, LID, PUSH>(c, ringA[s], ringB[s], F, ringC[s], ring7[s], ringC[s][2][0],
-                                        ring8[s], ringC[s][1][V - 1], fl, df_lid);
             // what the next rows need of row r
             bool rt, rb;
             wall_rows(r, rt, rb);
-            if (LID && rb) {
-                // row r is the bottom row: next iteration it bounces its own (4,7,8)
+            if (s < NLDS) {
+                // keep the LDS reads of this step from being hoisted above the previous step's
+                // arithmetic: hoisted, every LDS ring costs 18 more live registers and the kernel spills
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t par = i & 1u;           // set `par` holds row r-2, set `par^1` row r-1
+                T A[3][V], B[3][V], C[3][V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) { ringA[s][0][e] = o[4][e]; ringA[s][1][e] = o[7][e]; ringA[s][2][e] = o[8][e]; }
+                for (int k = 0; k < 3; ++k) {
+                    lds_get(A[k], s, par * 3 + k);
+                    lds_get(C[k], s, (par ^ 1u) * 3 + k);
+                    lds_get(B[k], s, 6 + k);
+                }
+                gather_row<T, V, LID, PUSH>(c, A, B, F, C, ring7[s], C[2][0], ring8[s], C[1][V - 1], fl, df_lid);
+                if (LID && rb) {
+                    // row r is the bottom row: next iteration it bounces its own (4,7,8)
+                    lds_put(s, (par ^ 1u) * 3 + 0, o[4]); lds_put(s, (par ^ 1u) * 3 + 1, o[7]); lds_put(s, (par ^ 1u) * 3 + 2, o[8]);
+                }
+                lds_put(s, par * 3 + 0, o[2]); lds_put(s, par * 3 + 1, o[5]); lds_put(s, par * 3 + 2, o[6]);
+                lds_put(s, 6 + 0, o[0]); lds_put(s, 6 + 1, o[1]); lds_put(s, 6 + 2, o[3]);
             } else {
+                constexpr int kNone = 0;
+                const int q = s >= NLDS ? s - NLDS : kNone;   // register ring of this step
+                gather_row<T, V, LID, PUSH>(c, ringA[q], ringB[q], F, ringC[q], ring7[s], ringC[q][2][0],
+                                            ring8[s], ringC[q][1][V - 1], fl, df_lid);
+                if (LID && rb) {
+                    // row r is the bottom row: next iteration it bounces its own (4,7,8)
 #pragma unroll
-                for (int e = 0; e < V; ++e) { ringA[s][0][e] = ringC[s][0][e]; ringA[s][1][e] = ringC[s][1][e]; ringA[s][2][e] = ringC[s][2][e]; }
-            }
+                    for (int e = 0; e < V; ++e) { ringA[q][0][e] = o[4][e]; ringA[q][1][e] = o[7][e]; ringA[q][2][e] = o[8][e]; }
+                } else {
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                ringB[s][0][e] = o[0][e]; ringB[s][1][e] = o[1][e]; ringB[s][2][e] = o[3][e];
-                ringC[s][0][e] = o[2][e]; ringC[s][1][e] = o[5][e]; ringC[s][2][e] = o[6][e];
+                    for (int e = 0; e < V; ++e) { ringA[q][0][e] = ringC[q][0][e]; ringA[q][1][e] = ringC[q][1][e]; ringA[q][2][e] = ringC[q][2][e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    ringB[q][0][e] = o[0][e]; ringB[q][1][e] = o[1][e]; ringB[q][2][e] = o[3][e];
+                    ringC[q][0][e] = o[2][e]; ringC[q][1][e] = o[5][e]; ringC[q][2][e] = o[6][e];
+                }
             }
             ring7[s] = o[7][0];
             ring8[s] = o[8][V - 1];
@@ -409,19 +462,11 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 }
 
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
-// scalar bookkeeping, memory issue and hazard stalls with vector work.  Every instantiation but the
-// fp64 lid-driven K=4 ones fits (or spills a handful of loop-invariant values).
+// scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
+// every instantiation fits without spilling (157-256 VGPRs).
 template <typename T, int V, int K, bool PUSH, bool LID>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
-{
-    fused_body<T, V, K, PUSH, LID>(f, buf, g, om, df_lid);
-}
-
-// The same sweep without the register cap (one wavefront per SIMD if it needs more than 256 VGPRs).
-template <typename T, int V, int K, bool PUSH, bool LID>
-__global__ void __launch_bounds__(kWave)
-k_fused_wide(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     fused_body<T, V, K, PUSH, LID>(f, buf, g, om, df_lid);
 }

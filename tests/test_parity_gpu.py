@@ -69,7 +69,7 @@ def test_long_run_1000_steps(dtype, scene, scheme, monkeypatch):
     ref, _ = orc.run(scene, scheme, nx, ny, 1000, omega, dtype)
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
-    assert sim.launches == 250
+    assert sim.launches == (250 if dtype == np.float64 else 167)   # runs of 4 (fp64) or 6 (fp32) steps
     assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 4")
     # the same run with a size threshold that sends this lattice to the one-step sweeps
     monkeypatch.setenv("LBM_FUSED_MIN_NODES", "1000000")
@@ -199,7 +199,7 @@ def test_slab_simulation_single_rank_equals_plain_simulation():
         for dtype in (torch.float32, torch.float64):
             a = Simulation(256, 40, scene=scene, scheme=scheme, dtype=dtype, omega=1.1)
             a.step(37)
-            for halo in (1, 2, 4):   # one halo row per step; deep halos with fused blocks of steps
+            for halo in (1, 2, 4) + ((6,) if dtype == torch.float32 else ()):   # one halo row per step; deep halos, fused blocks
                 b = SlabSimulation(256, 40, scene=scene, scheme=scheme, dtype=dtype, omega=1.1, halo=halo)
                 b.step(37)
                 assert torch.equal(a.f, b.interior()), (scene, scheme, dtype, halo)

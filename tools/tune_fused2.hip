@@ -32,18 +32,16 @@ __global__ void k_diff(const T *a, const T *b, size_t n, unsigned long long *cnt
 
 struct Variant { std::string name; int K; double lups; std::function<void()> launch; std::vector<float> ms; };
 
-template <typename T, int V, int K, bool PUSH, int H>
-void add_fused(std::vector<Variant> &vs, T *a, T *b, uint32_t nx, uint32_t ny, T om, uint32_t seg_rows, int wpc)
+template <typename T, int V, int K, bool PUSH>
+void add_fused(std::vector<Variant> &vs, T *a, T *b, uint32_t nx, uint32_t ny, T om, uint32_t seg_rows)
 {
-    constexpr int W = 64 - 2 * H;
-    FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0};
-    auto kern = k_fused<T, V, K, PUSH, false, H>;
-    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const size_t lds = (wpc >= 32) ? 0 : (160 * 1024 / wpc) & ~255u;
+    constexpr int W = 64 - 2 * fused_halo_lanes<T, V>();
+    FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0, 0};
+    auto kern = k_fused<T, V, K, PUSH, false>;
     const dim3 grid(g.nstrips * g.nsegs);
     char nm[96];
-    snprintf(nm, sizeof nm, "K%d_%s_f%d_V%d_H%d_S%u_w%d", K, PUSH ? "push" : "pull", (int)sizeof(T) * 8, V, H, seg_rows, wpc);
-    vs.push_back({nm, K, (double)nx * ny * K, [=] { hipLaunchKernelGGL(kern, grid, dim3(64), lds, 0, a, b, g, om, (T)0); }, {}});
+    snprintf(nm, sizeof nm, "K%d_%s_f%d_V%d_S%u", K, PUSH ? "push" : "pull", (int)sizeof(T) * 8, V, seg_rows);
+    vs.push_back({nm, K, (double)nx * ny * K, [=] { hipLaunchKernelGGL(kern, grid, dim3(64), 0, 0, a, b, g, om, (T)0); }, {}});
 }
 
 template <typename T, int V, bool PUSH>
@@ -86,14 +84,14 @@ int run(uint32_t nx, uint32_t ny, int rounds, int iters, const char *only)
     unsigned long long *cnt; CK(hipMalloc(&cnt, 8));
     std::vector<Variant> vs;
     constexpr int V2 = VP / 2;
-    for (uint32_t S : {32u, 64u}) {
-        add_fused<T, VP, 4, PUSH, 2>(vs, a, b, nx, ny, om, S, 8);
-        add_fused<T, V2, 4, PUSH, 4>(vs, a, b, nx, ny, om, S, 8);
-        add_fused<T, V2, 4, PUSH, 4>(vs, a, b, nx, ny, om, S, 12);
-        add_fused<T, VP, 3, PUSH, 2>(vs, a, b, nx, ny, om, S, 8);
-        add_fused<T, V2, 3, PUSH, 4>(vs, a, b, nx, ny, om, S, 8);
-        add_fused<T, V2, 3, PUSH, 4>(vs, a, b, nx, ny, om, S, 12);
-        add_fused<T, V2, 2, PUSH, 4>(vs, a, b, nx, ny, om, S, 12);
+    for (uint32_t S : {128u, 192u}) {
+        add_fused<T, V2, 4, PUSH>(vs, a, b, nx, ny, om, S);
+        if constexpr (sizeof(T) == 4) {
+            add_fused<T, V2, 5, PUSH>(vs, a, b, nx, ny, om, S);
+            add_fused<T, V2, 6, PUSH>(vs, a, b, nx, ny, om, S);
+            add_fused<T, V2, 7, PUSH>(vs, a, b, nx, ny, om, S);
+            add_fused<T, V2, 8, PUSH>(vs, a, b, nx, ny, om, S);
+        }
     }
     if (only) {
         std::vector<Variant> keep;
