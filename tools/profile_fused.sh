@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_fused
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 60 --warmup 12 --no-cpu-baseline"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || exit 1
