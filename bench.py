@@ -209,7 +209,7 @@ def main():
     if rank == 0:
         updates = nx * ny_glob * args.steps
         mlups = updates / elapsed / 1e6
-        # dominant kernel = the (interior) sweep: one launch per run of up to four time steps
+        # dominant kernel = the (interior) sweep: one launch per run of up to six time steps
         n_launch = launches() - launches0
         steps_per_launch = args.steps / n_launch
         launch_s = dev_ms * 1e-3 / n_launch

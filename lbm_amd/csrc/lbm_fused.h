@@ -2,7 +2,7 @@
 //
 // A single collide-and-stream step moves 18 populations per node through HBM for ~110 flops: the
 // one-step sweeps of lbm_device.h sit at the memory roofline with the vector ALUs 80 % idle.  These
-// kernels advance K = 2..4 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
+// kernels advance K = 1..6 (fp64: 1..4) steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
 // ...) while reading every population once and writing it once:
 //
 //   * one wavefront owns a strip of 64 x 8 bytes of a row and marches it through a segment of
@@ -11,12 +11,13 @@
 //     memory stalls (measured 62 % VALU-active at K=4 with 16-byte lanes and 440 VGPRs); with half
 //     the nodes per lane the K=4 pull kernel fits 256 VGPRs, two wavefronts share a SIMD and the
 //     fp32 sweep gains 11 % (211 -> 234 GLUPS at 16384^2);
-//   * the time levels between the loaded and the stored one never leave the register file: per
-//     level a ring of nine vectors holds the populations that the next rows still need ((2,5,6) of
-//     two rows, (0,1,3) of one row), so iteration i relaxes row R at level 1, row R-1 at level 2,
-//     ... and stores row R-K+1 at level K;
+//   * the time levels between the loaded and the stored one never reach memory: per level a ring
+//     of nine vectors holds the populations that the next rows still need ((2,5,6) of two rows,
+//     (0,1,3) of one row), so iteration i relaxes row R at level 1, row R-1 at level 2, ... and
+//     stores row R-K+1 at level K.  The last two rings sit in registers, earlier ones in LDS that
+//     only this wavefront touches;
 //   * the x neighbours that the streaming step needs come from the adjacent lanes through DPP
-//     wavefront shifts -- no LDS, no barriers, every global access a naturally aligned 16 bytes;
+//     wavefront shifts -- no barriers, every global access a naturally aligned 8 bytes;
 //   * the dependency cone is paid for with redundant work at the strip and segment edges: four
 //     lanes (32 bytes) of x halo per side, so that the 56 stored lanes of a strip cover whole
 //     64-byte lines (partially written lines cost 20 % of the achieved HBM rate), and K or K-1 rows
@@ -28,7 +29,7 @@
 // more than that saves (fp32 K=4: 245 -> 227 / 222 GLUPS, fp64 131 -> 115 / 112).
 //
 // Pull scheme (stored state: post-collision populations):  [gather from memory, relax] then K-1 x
-// [gather from registers, relax], store.   Push scheme (stored state: post-streaming populations):
+// [gather from the rings, relax], store.   Push scheme (stored state: post-streaming populations):
 // [relax the loaded row] then K-1 x [gather, relax], one more gather, store.
 //
 // Lid-driven cavity: the gathers apply the half-way bounce-back map of pull-push.cpp:496-528 read

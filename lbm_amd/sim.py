@@ -54,7 +54,7 @@ class Simulation:
         self.f = torch.empty((9, self.ny, self.nx), dtype=dtype, device=self.device)
         self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
         self.t = 0
-        self.launches = 0   # sweep launches so far (a launch advances 1..4 steps)
+        self.launches = 0   # sweep launches so far (a launch advances 1..6 steps)
         self._vel: Optional[torch.Tensor] = None
         self._mag: Optional[torch.Tensor] = None
         if scene == LID_DRIVEN:

@@ -49,7 +49,7 @@ CASES = [("shear", "pull"), ("shear", "push"), ("lid", "push"), ("lid", "pull")]
 @pytest.mark.parametrize("max_fuse", [1, None], ids=["one-step", "fused"])
 def test_populations_match_oracle_bit_for_bit(dtype, scene, scheme, nx, ny, max_fuse):
     """max_fuse=1: one launch of the one-step sweep per time step; None: the time loop's default
-    (runs of up to four steps per fused launch where the row length allows it)."""
+    (runs of up to six steps per fused launch where the row length allows it)."""
     for omega in (0.5, 1.0, 1.7):
         sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
         ref, _ = orc.run(scene, scheme, nx, ny, 0, omega, dtype)
