@@ -136,8 +136,8 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * Returns LBM_ERR_UNSUPPORTED (nothing launched) when rows are not a whole number of 8-byte
  * vectors (odd nx in fp32); callers then take nsteps one-step sweeps. */
 
-/* Largest nsteps the fused entry points accept for this precision and row length: 6 in fp32, 4 in
- * fp64, 1 = row length unsupported. */
+/* Largest nsteps the fused entry points accept for this precision and row length: 6, or 1 when
+ * the row length is unsupported. */
 int lbm_fused_max_steps(int prec, uint64_t nx);
 
 /* How many of the `remaining` iterations of the time loop the next call should take for a lattice

@@ -384,8 +384,7 @@ int fused_xcd_default()
 }
 int g_fused_xcd = fused_xcd_default();
 
-// the x halo of a strip (32 bytes) holds 8 fp32 or 4 fp64 nodes, one per fused step
-int max_fused_steps(int prec) { return prec == LBM_F32 ? lbm::kFusedMaxStepsF32 : lbm::kFusedMaxSteps; }
+int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
 
@@ -400,7 +399,8 @@ template <typename T, int V, bool PUSH, bool LID>
 int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
-    constexpr uint64_t W = lbm::kWave - 2 * lbm::fused_halo_lanes<T, V>();
+    // lanes stored per strip: 56, or 48 for fp64 beyond four steps (wider x halo)
+    const uint64_t W = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>() : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
     uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 128);
@@ -441,14 +441,9 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         LBM_FUSED_CASE(2)
         LBM_FUSED_CASE(3)
         LBM_FUSED_CASE(4)
-        case 5: case 6:
-            if constexpr (sizeof(T) == 4) {
-                if (k == 5) hipLaunchKernelGGL((lbm::k_fused<T, V, 5, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
-                else        hipLaunchKernelGGL((lbm::k_fused<T, V, 6, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df);
-                break;
-            }
-            return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d is available in fp32 only", k);
-        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxStepsF32);
+        LBM_FUSED_CASE(5)
+        LBM_FUSED_CASE(6)
+        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
     }
 #undef LBM_FUSED_CASE
     return launch_status("fused sweep");

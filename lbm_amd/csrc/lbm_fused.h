@@ -2,7 +2,7 @@
 //
 // A single collide-and-stream step moves 18 populations per node through HBM for ~110 flops: the
 // one-step sweeps of lbm_device.h sit at the memory roofline with the vector ALUs 80 % idle.  These
-// kernels advance K = 1..6 (fp64: 1..4) steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
+// kernels advance K = 1..6 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
 // ...) while reading every population once and writing it once:
 //
 //   * one wavefront owns a strip of 64 x 8 bytes of a row and marches it through a segment of
@@ -19,9 +19,9 @@
 //   * the x neighbours that the streaming step needs come from the adjacent lanes through DPP
 //     wavefront shifts -- no barriers, every global access a naturally aligned 8 bytes;
 //   * the dependency cone is paid for with redundant work at the strip and segment edges: four
-//     lanes (32 bytes) of x halo per side, so that the 56 stored lanes of a strip cover whole
-//     64-byte lines (partially written lines cost 20 % of the achieved HBM rate), and K or K-1 rows
-//     of y halo per segment end;
+//     lanes (32 bytes) of x halo per side -- eight for fp64 beyond four steps, one node per step --
+//     so that the 56 (48) stored lanes of a strip cover whole 64-byte lines (partially written
+//     lines cost 20 % of the achieved HBM rate), and K or K-1 rows of y halo per segment end;
 //   * arithmetic per node and time step is the one-step kernels' `collide`, in the same order, so
 //     the result is bit-identical to K one-step sweeps.
 // Tried and rejected: strips shared by 2 or 4 wavefronts (boundary scalars through LDS, one barrier
@@ -52,10 +52,14 @@
 namespace lbm {
 
 constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node
-constexpr int kFusedHaloBytes = 32;  // x halo on either side of a strip: stored lanes then cover whole 64-byte lines
-constexpr int kFusedMaxSteps = 4;    // one node of halo per step must fit in the halo (fp64: 4 nodes)
-constexpr int kFusedMaxStepsF32 = 6; // fp32 halos hold 8 nodes; beyond four steps the early rings move to LDS
-template <typename T, int V> constexpr int fused_halo_lanes() { return kFusedHaloBytes / (V * (int)sizeof(T)); }
+constexpr int kFusedHaloBytes = 32;  // granule of the x halo on either side of a strip: stored lanes then cover whole 64-byte lines
+constexpr int kFusedMaxSteps = 6;    // more steps gain nothing (16384^2 fp32 pull K=6/7/8: 280/284/274 GLUPS, push
+                                     // 279/265/236; fp64 pull 138/141/135, push 132/129/117)
+// halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules
+template <typename T, int V, int K> constexpr int fused_halo_lanes()
+{
+    return ((K * (int)sizeof(T) + kFusedHaloBytes - 1) / kFusedHaloBytes) * kFusedHaloBytes / (V * (int)sizeof(T));
+}
 
 struct FusedGeom {
     uint32_t nx, ny;        // row length, rows in the array
@@ -195,7 +199,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                                            const T om, const T df_lid)
 {
     static_assert(V * sizeof(T) == kFusedLaneBytes, "a lane owns kFusedLaneBytes of a row");
-    constexpr int H = fused_halo_lanes<T, V>();
+    constexpr int H = fused_halo_lanes<T, V, K>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
     constexpr int NG = PUSH ? K : K - 1;     // streaming steps done in registers

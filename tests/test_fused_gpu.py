@@ -56,8 +56,6 @@ SIZES = [(8, 3), (8, 1), (64, 48), (112, 9), (114, 7), (1024, 70), (2048, 5), (4
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
 def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
     from lbm_amd import ops
-    if k > 4 and dtype == np.float64:
-        pytest.skip("five and six fused steps exist in fp32 only (the x halo holds four fp64 nodes)")
     rng = np.random.default_rng(7 * k + (dtype == np.float64))
     for nx, ny in SIZES:
         if scene == "lid" and (ny < 2 or nx < 2):
@@ -80,8 +78,6 @@ def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
 def test_periodic_row_range_with_deep_ghost_rows(dtype, scheme, k):
     """wrap_y = 0: rows [k, ny-k) advance from an array whose outer k rows are ghost rows; rows
     outside the range must not be written."""
-    if k > 4 and dtype == np.float64:
-        pytest.skip("fp32 only")
     rng = np.random.default_rng(100 + k)
     for nx, ny in ((256, 21), (1024, 40), (64, 2 * k + 1)):
         f = random_state(rng, nx, ny, dtype)
@@ -100,8 +96,6 @@ def test_periodic_row_range_with_deep_ghost_rows(dtype, scheme, k):
 def test_lid_slab_of_a_taller_cavity(dtype, scheme, k):
     """A slab holds global rows [g0 - ghosts, g1 + ghosts) of a cavity of height 40; slabs at the
     bottom wall, in the middle and under the lid."""
-    if k > 4 and dtype == np.float64:
-        pytest.skip("fp32 only")
     rng = np.random.default_rng(200 + k)
     nx, ny_glob = 256, 40
     f = random_state(rng, nx, ny_glob, dtype)
@@ -130,9 +124,7 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
     assert_bits_equal(d_b.cpu().numpy(), want, "nsteps=1")
     assert ops.fused_max_steps(d_f) == 6
     odd = torch.zeros((9, 4, 67), dtype=torch.float64, device="cuda")
-    assert ops.fused_max_steps(odd) == 4      # one fp64 node per lane: any row length
-    with pytest.raises(capi.LbmError):
-        ops.pull_periodic_fused(odd, torch.zeros_like(odd), 0.7, 0, 4, True, 5)     # fp64 stops at four steps
+    assert ops.fused_max_steps(odd) == 6      # one fp64 node per lane: any row length
     odd = torch.zeros((9, 4, 66), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(odd) == 6
     odd = torch.zeros((9, 4, 67), dtype=torch.float32, device="cuda")

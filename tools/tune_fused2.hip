@@ -35,7 +35,7 @@ struct Variant { std::string name; int K; double lups; std::function<void()> lau
 template <typename T, int V, int K, bool PUSH>
 void add_fused(std::vector<Variant> &vs, T *a, T *b, uint32_t nx, uint32_t ny, T om, uint32_t seg_rows)
 {
-    constexpr int W = 64 - 2 * fused_halo_lanes<T, V>();
+    constexpr int W = 64 - 2 * fused_halo_lanes<T, V, K>();
     FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0, 0};
     auto kern = k_fused<T, V, K, PUSH, false>;
     const dim3 grid(g.nstrips * g.nsegs);
@@ -86,9 +86,9 @@ int run(uint32_t nx, uint32_t ny, int rounds, int iters, const char *only)
     constexpr int V2 = VP / 2;
     for (uint32_t S : {128u, 192u}) {
         add_fused<T, V2, 4, PUSH>(vs, a, b, nx, ny, om, S);
-        if constexpr (sizeof(T) == 4) {
-            add_fused<T, V2, 5, PUSH>(vs, a, b, nx, ny, om, S);
-            add_fused<T, V2, 6, PUSH>(vs, a, b, nx, ny, om, S);
+        add_fused<T, V2, 5, PUSH>(vs, a, b, nx, ny, om, S);
+        add_fused<T, V2, 6, PUSH>(vs, a, b, nx, ny, om, S);
+        if constexpr (sizeof(T) == 8) {
             add_fused<T, V2, 7, PUSH>(vs, a, b, nx, ny, om, S);
             add_fused<T, V2, 8, PUSH>(vs, a, b, nx, ny, om, S);
         }
