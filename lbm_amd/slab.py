@@ -9,7 +9,7 @@ pair is already contiguous, so the three populations that cross a slab edge are 
 main.cpp:238-273, :339-374).
 
 Two schedules share this layout.  Lattices that stream from HBM (and whose rows are whole 16-byte
-vectors) run the deep-halo schedule: G = 6 (fp64: 4) ghost rows per side hold plain copies of the neighbour's
+vectors) run the deep-halo schedule: G = 6 ghost rows per side hold plain copies of the neighbour's
 edge rows, a block of up to G time steps is advanced by one fused launch per region (see
 csrc/lbm_fused.h: every population crosses HBM once per block, not once per step), and ghost rows
 are refreshed once per block -- nine contiguous G-row messages per direction.  Everything else
