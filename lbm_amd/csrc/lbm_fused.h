@@ -177,13 +177,13 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
     }
 }
 
-// PAIRS: explicit packed pairs for fp32 (7 % faster in the periodic sweeps: 240 -> 256 GLUPS at
-// 16384^2).  The lid-driven instantiations sit at the 256-register cap and spill with it (230 -> 197),
-// so they leave the pairing to the compiler.
-template <typename T, int V, bool PAIRS>
+// fp32 nodes are relaxed in explicit packed pairs (collide_nodes): 7 % faster than leaving the pairing
+// to the compiler in the periodic sweeps (240 -> 256 GLUPS at 16384^2, four steps), 4-10 % in the
+// lid-driven ones.
+template <typename T, int V>
 __device__ __forceinline__ void relax_row(T (&o)[9][V], const T (&c)[9][V], const T om)
 {
-    collide_nodes<T, V, PAIRS>(o, c, om);
+    collide_nodes<T, V>(o, c, om);
 }
 
 // One row of input as it sits in registers between its load and its use.
@@ -359,7 +359,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         const int64_t Rc = (int64_t)ys - D + (int64_t)i;
         T o[9][V];
         if (PUSH) {
-            relax_row<T, V, !LID>(o, in.v, om);
+            relax_row<T, V>(o, in.v, om);
         } else {
             T A[3][V], B[3][V], F[3][V], c[9][V];
 #pragma unroll
@@ -372,7 +372,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
             wall_rows(Rc, fl.t, fl.b);
             // at the lid the F slots were loaded with the row's own (2,5,6)
             gather_row<T, V, LID, false>(c, A, B, F, F, in.w[0], in.w[1], in.w[2], in.w[3], fl, df_lid);
-            relax_row<T, V, !LID>(o, c, om);
+            relax_row<T, V>(o, c, om);
         }
 #pragma unroll
         for (int s = 0; s < NG; ++s) {
@@ -431,7 +431,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 #pragma unroll
                     for (int e = 0; e < V; ++e) o[q][e] = c[q][e];
             } else {
-                relax_row<T, V, !LID>(o, c, om);
+                relax_row<T, V>(o, c, om);
             }
         }
         if (i >= (uint32_t)(D + NG) && store_lane) {
