@@ -19,8 +19,8 @@ CASES = [
     ("shear", "pull", "float32", 256, 37, 30, 0.8),
     ("shear", "push", "float32", 256, 37, 30, 0.8),
     ("shear", "pull", "float64", 64, 24, 40, 1.3),
-    ("lid", "push", "float64", 64, 23, 50, 1.1),
-    ("lid", "pull", "float32", 128, 21, 50, 1.7),
+    ("lid", "push", "float64", 64, 25, 50, 1.1),
+    ("lid", "pull", "float32", 128, 27, 50, 1.7),
 ]
 
 
@@ -33,7 +33,7 @@ def _worker(rank, world, store_path, out_path):
     try:
         for case in CASES:
             scene, scheme, tdt, nx, ny, steps, omega = case
-            for halo in (1, 4):   # one halo row per step / deep halo, blocks of four fused steps
+            for halo in (1, 4, 6):   # one halo row per step / deep halos, blocks of four or six fused steps
                 sim = SlabSimulation(nx, ny, scene=scene, scheme=scheme, dtype=getattr(torch, tdt), omega=omega,
                                      device="cuda:0", halo=halo)
                 sim.step(steps)
@@ -59,7 +59,8 @@ def _worker_big(rank, world, store_path, out_dir):
     ok = True
     try:
         for scheme, overlap, halo in (("pull", True, 1), ("push", True, 1), ("pull", False, 1),
-                                      ("pull", True, 4), ("push", True, 4), ("push", False, 4)):
+                                      ("pull", True, 4), ("push", True, 4), ("push", False, 4),
+                                      ("pull", True, None), ("push", True, 6)):
             nx, ny, steps, omega = 8192, 1024, 14, 0.5
             sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=torch.float32, omega=omega,
                                  device="cuda:0", overlap=overlap, halo=halo)
@@ -102,7 +103,9 @@ def _worker_rccl_self(rank, world, port, out_dir):
                                                ("pull", torch.float32, np.float32, 8192, 512, 4),
                                                ("push", torch.float32, np.float32, 8192, 512, 4),
                                                ("pull", torch.float64, np.float64, 4096, 256, 4),
-                                               ("push", torch.float64, np.float64, 1030, 64, 3)):
+                                               ("push", torch.float64, np.float64, 1030, 64, 3),
+                                               ("pull", torch.float32, np.float32, 8192, 512, None),
+                                               ("push", torch.float64, np.float64, 4096, 256, 6)):
             steps, omega = 15, 0.7
             sim = SlabSimulation(nx, ny, scene="shear", scheme=scheme, dtype=tdt, omega=omega, device="cuda:0",
                                  p2p_to_self=True, halo=halo)
@@ -140,7 +143,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_oracle():
         scene, scheme, tdt, nx, ny, steps, omega = case
         ndt = np.float32 if tdt == "float32" else np.float64
         want, _ = orc.run(scene, scheme, nx, ny, steps, omega, ndt)
-        for halo in (1, 4):
+        for halo in (1, 4, 6):
             got, vmax = results[case + (halo,)]
             assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (case, halo)
             assert vmax == float(orc.max_velocity(want)), (case, halo)
