@@ -67,6 +67,8 @@ CASES = [
     ("lid", "push", "float64", 12, 26, 31, 1.1, 4),
     ("lid", "pull", "float64", 12, 26, 31, 1.1, 4),
     ("lid", "push", "float32", 8, 13, 30, 1.7, 2),
+    ("shear", "push", "float32", 16, 37, 27, 0.8, 6),
+    ("lid", "pull", "float64", 12, 36, 20, 1.1, 6),   # slabs of exactly 2 x depth rows (world 3)
 ]
 
 
