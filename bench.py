@@ -264,6 +264,10 @@ def main():
                 "min_bytes_per_launch": min_bytes,
                 "hbm_frac": (traffic if traffic else min_bytes) / launch_s / 1e9 / HBM_PEAK_GBS,
                 "launch_ms": launch_s * 1e3,
+                "note": ("one launch advances several time steps per pass over HBM, so the algorithmic rate "
+                         "(72/144 B per node and step) can exceed the HBM peak; hbm_frac prices the bytes "
+                         "actually moved (traffic if profiled, else min_bytes_per_launch)") if k_dom != 1 else
+                        "one time step per launch",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
