@@ -139,3 +139,29 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
         ops.push_lid_fused(d_f, d_b, 0.7, 1.0, 0.1, 1, 11, 5, 40, 2)                # ghost rows too shallow
     with pytest.raises(capi.LbmError):
         ops.pull_periodic_fused(d_f, d_f, 0.7, 0, 12, True, 2)                      # overlap
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_extreme_aspect_ratios_fused_equals_one_step(dtype):
+    """Very long rows (thousands of strips) and very tall, narrow lattices (thousands of segments):
+    six fused steps against six launches of the one-step sweeps, which the oracle tests pin."""
+    from lbm_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for nx, ny in ((262144, 20), (6, 50000), (131070, 7)):
+        f = 1.0 / 9 + 0.02 * torch.randn((9, ny, nx), dtype=dtype, device="cuda", generator=gen)
+        for scene in ("shear", "lid"):
+            for scheme in ("pull", "push"):
+                a, b = f.clone(), torch.empty_like(f)
+                for _ in range(6):
+                    if scene == "shear":
+                        getattr(ops, f"{scheme}_periodic_no_mpi")(a, b, nx, ny, 1.2)
+                    else:
+                        getattr(ops, f"{scheme}_lid_driven")(a, b, nx, ny, 1.2, 1.0, 0.1)
+                    a, b = b, a
+                got = torch.full_like(f, float("nan"))
+                if scene == "shear":
+                    getattr(ops, f"{scheme}_periodic_fused")(f, got, 1.2, 0, ny, True, 6)
+                else:
+                    getattr(ops, f"{scheme}_lid_fused")(f, got, 1.2, 1.0, 0.1, 0, ny, 0, ny, 6)
+                bits = torch.int32 if dtype == torch.float32 else torch.int64
+                assert bool((got.view(bits) == a.view(bits)).all()), (scene, scheme, nx, ny)
