@@ -66,3 +66,34 @@ def test_viscosity_push_matches_pull():
     b = run_series(0.6, 400, 400, 500, 20001, extra=("-push",))
     assert abs(fit_nu(ts, a, 400) - fit_nu(ts, b, 400)) < 1e-4
     assert abs(fit_nu(ts, a, 400) - (1 / 0.6 - 0.5) / 3) < 2e-3
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp64"])
+def test_baseline_config1_series(golden_dir, prec):
+    """`-nx 1024 -ny 1024 -w 0.5 -s 50000 -of 500 -omv` (pull): the 100 values the reference's own
+    sources print for this command (tests/golden/config1_series.json), and the viscosity fitted
+    from them as shear-wave.py:78-80 fits it (analytic 0.5)."""
+    import torch
+    from lbm_amd import Simulation
+    with open(os.path.join(golden_dir, "config1_series.json")) as fh:
+        gold = json.load(fh)
+    want_text = gold[f"{prec}_text"]
+    want = np.array([float(v) for v in want_text.split(",")[:-1]])
+    sim = Simulation(1024, 1024, scene="shear", scheme="pull", omega=0.5,
+                     dtype=torch.float32 if prec == "fp32" else torch.float64)
+    text = sim.run(50000, 500, "omv")
+    got = np.array([float(v) for v in text.split(",")[:-1]])
+    assert got.shape == want.shape == (100,)
+    if prec == "fp64":
+        # contraction moves fp64 results by ~1e-15: the printed six digits are the same text, bar a
+        # value that sits on a rounding boundary of the sixth digit
+        same = sum(a == b for a, b in zip(text.split(","), want_text.split(",")))
+        assert same >= 99, (same, text[:80], want_text[:80])
+        np.testing.assert_allclose(got, want, rtol=2e-6)
+    else:
+        # the recording build contracted a*b+c, this one does not (measured: <= 2.4e-5 relative)
+        np.testing.assert_allclose(got, want, rtol=1e-4)
+    ts = np.arange(0, 50000, 500, dtype=np.float64)
+    nu = fit_nu(ts, got, 1024)
+    assert abs(nu - 0.5) < 1e-3
+    assert abs(nu - gold["fit_nu"][prec]) < 3e-4
