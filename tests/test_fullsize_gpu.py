@@ -97,3 +97,21 @@ def test_pull_and_push_velocities_agree_at_full_size():
     assert float((va - vb).abs().max()) < 5e-7
     del a, b, va, vb
     _free()
+
+
+@pytest.mark.parametrize("scheme", ["push", "pull"])
+def test_config2_lid_cavity_1024sq_fp32_equals_oracle(scheme):
+    """BASELINE config 2 (`-ld -nx 1024 -ny 1024 -u 0.1`, fp32): populations and the velocity field
+    after 3000 steps, bit for bit against the CPU oracle run of the whole cavity (the reference's
+    command runs 10000 steps; the oracle would need half a minute of host time for that)."""
+    from lbm_amd import Simulation
+    nx = ny = 1024
+    steps, omega = 3000, 0.5
+    sim = Simulation(nx, ny, scene="lid", scheme=scheme, dtype=torch.float32, omega=omega, rho=1.0, u=0.1)
+    sim.step(steps)
+    want, _ = orc.run("lid", scheme, nx, ny, steps, omega, np.float32, rho=1.0, u=0.1)
+    got = sim.f.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    vel = sim.velocities().cpu().numpy()
+    assert np.array_equal(vel.view(np.uint32), orc.compute_velocities(want).view(np.uint32))
+    assert sim.max_velocity() == float(orc.max_velocity(want))
