@@ -22,6 +22,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lbm_hip.h"
@@ -192,22 +193,53 @@ static inline int fmt_g(char *dst, size_t cap, FLT v) { return std::snprintf(dst
 // check_nan: the -ov path stops at the first NaN, having already printed what precedes it.
 static bool write_block(std::ostream &os, const FLT *a, UINT nx, UINT ny, bool check_nan)
 {
-    std::string line;
-    char tmp[64];
-    for (UINT y = 0; y < ny; ++y) {
-        line.clear();
-        for (UINT x = 0; x < nx; ++x) {
-            const FLT v = a[y * nx + x];
-            if (check_nan && v != v) {
-                os << line;
-                std::cerr << "NaN encountered at x=" << x << " y=" << y << std::endl;
-                return false;
+    // where the scan order of io.cpp:236-243 meets the first NaN (ny*nx = none)
+    UINT stop = nx * ny;
+    if (check_nan)
+        for (UINT i = 0; i < nx * ny; ++i)
+            if (a[i] != a[i]) { stop = i; break; }
+    const UINT full_rows = stop / nx;          // rows printed whole
+    // Formatting is the expensive part of an output step (a million "%g" per 1024^2 frame): rows
+    // are formatted by a few host threads into per-chunk strings and written in order.
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+    if ((UINT)nthreads > full_rows) nthreads = full_rows ? (unsigned)full_rows : 1;
+    std::vector<std::string> chunks(nthreads);
+    auto format_rows = [&](unsigned t) {
+        const UINT y0 = full_rows * t / nthreads, y1 = full_rows * (t + 1) / nthreads;
+        std::string &out = chunks[t];
+        out.reserve((size_t)(y1 - y0) * nx * 10);
+        char tmp[64];
+        for (UINT y = y0; y < y1; ++y) {
+            for (UINT x = 0; x < nx; ++x) {
+                out.append(tmp, (size_t)fmt_g(tmp, sizeof tmp, a[y * nx + x]));
+                if (x < nx - 1) out.push_back(',');
             }
-            line.append(tmp, (size_t)fmt_g(tmp, sizeof tmp, v));
-            if (x < nx - 1) line.push_back(',');
+            out.push_back('\n');
         }
-        line.push_back('\n');
+    };
+    if (nthreads > 1) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(format_rows, t);
+        format_rows(0);
+        for (auto &th : pool) th.join();
+    } else {
+        format_rows(0);
+    }
+    for (const std::string &c : chunks) os << c;
+    if (stop < nx * ny) {
+        // the row that holds the NaN: what precedes it is printed, then the run ends (io.cpp:239-243)
+        std::string line;
+        char tmp[64];
+        const UINT y = full_rows, xn = stop % nx;
+        for (UINT x = 0; x < xn; ++x) {
+            line.append(tmp, (size_t)fmt_g(tmp, sizeof tmp, a[y * nx + x]));
+            line.push_back(',');
+        }
         os << line;
+        std::cerr << "NaN encountered at x=" << xn << " y=" << y << std::endl;
+        return false;
     }
     os << "#" << std::endl;
     return true;
