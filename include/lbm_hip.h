@@ -133,8 +133,8 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * Rows that the dependency cone of the updated rows reaches must be present in the array: with
  * wrap_y = 0 the periodic forms read rows [y_lo - nsteps, y_hi + nsteps) (deep ghost rows: copies of
  * the neighbouring slab's rows at time t), the lid forms the same range clipped at the walls.
- * Returns LBM_ERR_UNSUPPORTED (nothing launched) when rows are not a whole number of 8-byte
- * vectors (odd nx in fp32); callers then take nsteps one-step sweeps. */
+ * Returns LBM_ERR_UNSUPPORTED (nothing launched) for rows of a single node; callers then take
+ * nsteps one-step sweeps. */
 
 /* Largest nsteps the fused entry points accept for this precision and row length: 6, or 1 when
  * the row length is unsupported. */

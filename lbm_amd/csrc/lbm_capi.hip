@@ -388,11 +388,12 @@ int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
 
+// Rows of odd length in fp32 cannot be cut into 8-byte lanes; they run with one node per lane
+// (48 stored lanes per strip).  Anything from two nodes per row up is supported.
 template <typename T>
 bool fused_supported(uint64_t nx)
 {
-    constexpr int V = fused_width<T>();
-    return nx % V == 0 && nx >= 2 * V;
+    return nx >= 2;
 }
 
 template <typename T, int V, bool PUSH, bool LID>
@@ -461,6 +462,10 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const T rho = (T)rho_, u = (T)u_;
     const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
+    if constexpr (V8 > 1) {
+        if (nx % V8 != 0 || nx < 2 * V8)
+            return launch_fused<T, 1, PUSH, LID>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+    }
     return launch_fused<T, V8, PUSH, LID>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
 }
 
@@ -482,7 +487,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
                     "%d fused steps of rows [%llu,%llu) need %d ghost rows on either side inside [0,%llu)",
                     k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
     if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
-        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 8-byte vectors (nx=%llu)",
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -523,7 +528,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
                         (unsigned long long)need_lo, (unsigned long long)need_hi);
     }
     if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
-        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of whole 8-byte vectors (nx=%llu)",
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32

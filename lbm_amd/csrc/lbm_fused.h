@@ -198,7 +198,8 @@ template <typename T, int V, int K, bool PUSH, bool LID>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
-    static_assert(V * sizeof(T) == kFusedLaneBytes, "a lane owns kFusedLaneBytes of a row");
+    static_assert(V * sizeof(T) == kFusedLaneBytes || (V == 1 && sizeof(T) == 4),
+                  "a lane owns kFusedLaneBytes of a row (one fp32 node when rows have an odd length)");
     constexpr int H = fused_halo_lanes<T, V, K>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");

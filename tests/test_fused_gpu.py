@@ -45,10 +45,10 @@ def run_fused(scene, scheme, d_f, d_b, om, y_lo, y_hi, k, wrap_y=True, y_goff=0,
 
 
 # row lengths: one strip, a partial last strip, several strips (a strip stores 56 lanes = 112 fp32 /
-# 56 fp64 nodes), the shortest supported rows, odd lengths (fp64 only); heights: fewer rows than
-# steps (multiple wraps), one segment, several segments
+# 56 fp64 nodes; 48 lanes for odd fp32 rows and for fp64 beyond four steps), the shortest supported
+# rows, odd lengths; heights: fewer rows than steps (multiple wraps), one segment, several segments
 SIZES = [(8, 3), (8, 1), (64, 48), (112, 9), (114, 7), (1024, 70), (2048, 5), (4, 6), (724, 33), (2, 5), (57, 6),
-         (229, 11)]
+         (229, 11), (3, 4), (1027, 9)]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -66,7 +66,7 @@ def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
         d_f = torch.from_numpy(f).cuda()
         d_b = torch.full_like(d_f, float("nan"))
         if ops.fused_max_steps(d_f) == 1:
-            continue   # rows shorter than two 8-byte vectors
+            continue   # rows of a single node
         run_fused(scene, scheme, d_f, d_b, om, 0, ny, k, wrap_y=True, y_goff=0, ny_glob=ny)
         assert_bits_equal(d_b.cpu().numpy(), want, f"{scene}/{scheme} fused k={k} {nx}x{ny}")
         assert torch.equal(d_f.cpu(), torch.from_numpy(f)), "the input array was modified"
@@ -128,9 +128,11 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
     odd = torch.zeros((9, 4, 66), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(odd) == 6
     odd = torch.zeros((9, 4, 67), dtype=torch.float32, device="cuda")
-    assert ops.fused_max_steps(odd) == 1
+    assert ops.fused_max_steps(odd) == 6      # odd rows in fp32: one node per lane
+    one = torch.zeros((9, 4, 1), dtype=torch.float32, device="cuda")
+    assert ops.fused_max_steps(one) == 1
     with pytest.raises(capi.LbmError):
-        ops.pull_periodic_fused(odd, torch.zeros_like(odd), 0.7, 0, 4, True, 2)     # unsupported row length
+        ops.pull_periodic_fused(one, torch.zeros_like(one), 0.7, 0, 4, True, 2)     # unsupported row length
     with pytest.raises(capi.LbmError):
         ops.pull_periodic_fused(d_f, d_b, 0.7, 0, 12, True, 7)                      # too many steps
     with pytest.raises(capi.LbmError):
