@@ -24,7 +24,10 @@
 //     lines cost 20 % of the achieved HBM rate), and K or K-1 rows of y halo per segment end;
 //   * arithmetic per node and time step is the one-step kernels' `collide`, in the same order, so
 //     the result is bit-identical to K one-step sweeps.
-// Tried and rejected: strips shared by 2 or 4 wavefronts (boundary scalars through LDS, one barrier
+// Tried and rejected: leaving the streaming-step loop early while a segment ramps up (step s has
+// nothing real to do before iteration 2s) gains 2-4 % on 2048^2..4096^2 lattices but the extra
+// control flow costs 1.5-4 % on large ones (16384^2 fp32: 294 -> 290, lid 292 -> 280 GLUPS);
+// strips shared by 2 or 4 wavefronts (boundary scalars through LDS, one barrier
 // per streaming step) halve or quarter the x halo and the over-fetched lines, but the barriers cost
 // more than that saves (fp32 K=4: 245 -> 227 / 222 GLUPS, fp64 131 -> 115 / 112).
 //
