@@ -804,8 +804,10 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     // Five and six steps per launch pay off once the grid is large enough to keep the chip busy for
     // the longer ramp of a wavefront (fp32 pull, GLUPS at 4 / 6 steps: 512^2 47 / 35, 1024^2 108 / 92,
     // 1536^2 150 / 145, 2048^2 174 / 180, 4096^2 232 / 261, 8192^2 252 / 290, 16384^2 250 / 285).
+    // The smallest ones (fp32 pull, 3 / 4 steps: 256^2 17.1 / 16.7, 512^2 56 / 49, 1024^2 118 / 120) take three.
     uint64_t dflt = (uint64_t)kmax;
     if (dflt > 4 && nx * rows < (3ull << 20)) dflt = 4;
+    if (dflt > 3 && nx * rows < 600000ull) dflt = 3;
     const char *m = getenv("LBM_FUSED_MAX_STEPS");
     uint64_t k = m ? strtoull(m, nullptr, 10) : dflt;
     if (k < 1) k = 1;
