@@ -7,7 +7,7 @@
   * problem-size sweep: MLUPS of `-s 100 -of 0` runs over square lattices (problem-size.py:61-71).
 
 Runs on the HIP device through lbm_amd.Simulation; prints one table each.  Usage:
-    python tools/nu_sweep.py [--n 1000] [--steps 20000] [--omegas 0.2 0.6 1.0 1.4 1.8] [--sizes 1024 4096 16384]
+    python tools/nu_sweep.py [--n 1000] [--steps 200000] [--omegas 0.2 0.6 1.0 1.4 1.8] [--sizes 1024 4096 16384]
 """
 import argparse
 import os
@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=1000)
-    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=200000)   # shear-wave.py:60
     ap.add_argument("--every", type=int, default=500)
     ap.add_argument("--omegas", type=float, nargs="*", default=[0.2, 0.6, 1.0, 1.4, 1.8])
     ap.add_argument("--sizes", type=int, nargs="*", default=[1024, 2048, 4096, 8192, 16384])
