@@ -56,6 +56,8 @@ def parse():
                     help="strong scaling: fixed global height split over the ranks (overrides --ny-per-gpu), "
                          "e.g. --nx 32768 --ny-global 32768")
     ap.add_argument("--omega", type=float, default=0.5)
+    ap.add_argument("--layout", choices=["soa", "aos"], default="soa",
+                    help="aos = [NY][NX][9] arrays, the reference's COALESCING=false (single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU-baseline sample")
@@ -150,7 +152,7 @@ def main():
 
     if args.max_fuse:
         os.environ["LBM_FUSED_MAX_STEPS"] = str(args.max_fuse)   # read by lbm_plan_steps at every call
-    from lbm_amd import Simulation, SlabSimulation, capi
+    from lbm_amd import Simulation, SlabSimulation, capi, ops
     if args.threads_x or args.waves_per_cu:
         capi.call("lbm_set_launch_shape", args.threads_x, args.waves_per_cu)
 
@@ -163,6 +165,10 @@ def main():
         ny_glob = args.ny_global
         ny_loc = -(-ny_glob // world)   # the largest slab (remainder rows go to the lowest ranks)
 
+    if args.layout == "aos":
+        if world != 1 or args.slab:
+            raise SystemExit("--layout aos runs on one GPU without the slab path")
+        ops.set_layout("aos")
     if world == 1 and args.slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
@@ -218,7 +224,7 @@ def main():
         achieved = alg_bytes / launch_s / 1e9
         workload = (f"{'shear-wave decay' if args.scene == 'shear' else 'lid-driven cavity'} "
                     f"{nx}x{ny_glob} {args.precision} {args.scheme}")
-        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}"
+        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "")
         # profiles are keyed by the step count of the dominant launches (a run whose length is not a
         # multiple of it ends with one shorter launch)
         k_dom = min(args.steps, -(-args.steps // n_launch))
@@ -240,7 +246,7 @@ def main():
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL over gloo on shared GPUs: not a measurement)",
             "config": {
                 "workload": workload,
-                "scene": args.scene, "scheme": args.scheme, "nx": nx, "ny_global": ny_glob,
+                "scene": args.scene, "scheme": args.scheme, "layout": args.layout, "nx": nx, "ny_global": ny_glob,
                 "ny_per_gpu": ny_loc, "omega": args.omega,
                 "decomposition": ("single device" if world == 1 and not args.slab else
                                   f"{world} y-slab(s), {sim.G} ghost row(s) per edge refreshed every "

@@ -5,7 +5,8 @@
  * (reference: src/init.h, src/pull-push.h, src/io.h of JulianKarrer/lbm); the citation next to each
  * declaration names it.  Where the reference passes Kokkos View handles, this ABI takes the raw
  * device pointer of the same storage: populations are SoA [Q=9][NY][NX], x contiguous, element
- * (q,y,x) at ((q*NY)+y)*NX+x (reference global.h:37-41,112 with COALESCING=true, main.cpp:37-38).
+ * (q,y,x) at ((q*NY)+y)*NX+x (reference global.h:37-41,112 with COALESCING=true, main.cpp:37-38),
+ * unless lbm_set_layout selects the reference's other layout.
  * Where the reference passes scalars as rank-0 device Views (global.h:121-147) this ABI takes plain
  * values; they become kernel arguments.
  *
@@ -48,6 +49,17 @@ const char *lbm_status_string(int status);
 const char *lbm_last_error(void);
 /* ABI version; bumped when a signature changes. */
 int lbm_abi_version(void);
+
+/* The reference's COALESCING switch (macros.h:7, global.h:37-41) as a process-wide run-time setting.
+ * LBM_LAYOUT_SOA (default): [9][NY][NX].  LBM_LAYOUT_AOS: [NY][NX][9], element (q,y,x) at
+ * ((y*NX)+x)*9+q (main.cpp:34-35), for every distribution array passed to any entry point from
+ * then on.  In AOS the initialisers, the whole-lattice sweeps, the pull *_rows forms, every *_fused
+ * entry point and the velocity / max-|u| outputs work as documented; the push *_rows forms on a
+ * partial row range, the x-halo'd inner/outer forms and rows of one node return
+ * LBM_ERR_UNSUPPORTED.  Results are bit-identical to the SOA ones, node by node. */
+enum { LBM_LAYOUT_SOA = 0, LBM_LAYOUT_AOS = 1 };
+int lbm_set_layout(int layout);
+int lbm_get_layout(void);
 
 /* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
  * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (64, 128, 256 or 512) and the

@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "liblbm_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "lbm_capi.hip")]
-DEPS = SOURCES + [os.path.join(HERE, "csrc", "lbm_device.h"), os.path.join(ROOT, "include", "lbm_hip.h")]
+DEPS = SOURCES + [os.path.join(HERE, "csrc", "lbm_device.h"), os.path.join(HERE, "csrc", "lbm_fused.h"),
+                  os.path.join(ROOT, "include", "lbm_hip.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

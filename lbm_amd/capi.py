@@ -21,6 +21,8 @@ SIGNATURES = {
     "lbm_status_string": (C.c_char_p, [_int]),
     "lbm_last_error": (C.c_char_p, []),
     "lbm_abi_version": (_int, []),
+    "lbm_set_layout": (_int, [_int]),
+    "lbm_get_layout": (_int, []),
     "lbm_set_launch_shape": (_int, [_uint, _uint]),
     "lbm_init_shearwave": (_int, [_ptr, _int, _u64, _u64, _dbl, _dbl, _u64, _u64, _uint, _ptr]),
     "lbm_init_rest": (_int, [_ptr, _int, _u64, _u64, _dbl, _ptr]),

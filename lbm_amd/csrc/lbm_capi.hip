@@ -42,6 +42,9 @@ int fail(int status, const char *fmt, ...)
                         __FILE__, __LINE__);                                                  \
     } while (0)
 
+// memory layout of every distribution array passed in (lbm_set_layout)
+int g_layout = LBM_LAYOUT_SOA;
+
 // launch-shape hint (lbm_set_launch_shape)
 unsigned g_threads_x = 0;
 unsigned g_waves_per_cu = 0;
@@ -191,6 +194,14 @@ int launch_status(const char *what)
 
 template <typename T> constexpr int vec_width() { return 16 / (int)sizeof(T); }
 
+// One step on [NY][NX][9] arrays; defined with the multi-step sweeps, whose kernels it runs.
+template <bool PULL, bool LID>
+int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, double rho_eq,
+                 double u_lid, uint64_t y_lo, uint64_t y_hi, int wrap_y, int64_t y_goff, uint64_t ny_glob,
+                 void *stream);
+const char *const kAosNoHalo =
+    "the x-halo'd inner/outer forms exist only for [9][NY][NX] arrays (the reference's MPI path too, main.cpp:147)";
+
 // ---- periodic sweeps -------------------------------------------------------------------
 template <typename T, bool PULL>
 int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_,
@@ -237,6 +248,7 @@ int periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, 
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
     if (int s = check_rows(ny, y_lo, y_hi, !wrap_y)) return s;
+    if (g_layout == LBM_LAYOUT_AOS) return aos_one_step<PULL, false>(f, buf, prec, nx, ny, om, 0., 0., y_lo, y_hi, wrap_y, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
                ? sweep_periodic_rows<float, PULL>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, st)
@@ -264,6 +276,7 @@ int inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double o
           uint64_t LY, uint64_t HX, uint64_t HY, void *stream)
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (g_layout == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
     if (HX > nx || HY > ny || LX > HX || LY > HY)
         return fail(LBM_ERR_INVALID_ARGUMENT, "rectangle [%llu,%llu)x[%llu,%llu) outside %llux%llu",
                     (unsigned long long)LX, (unsigned long long)HX, (unsigned long long)LY,
@@ -289,6 +302,7 @@ template <bool PULL>
 int outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
+    if (g_layout == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
     if (nx < 4 || ny < 4)
         return fail(LBM_ERR_INVALID_ARGUMENT, "outer ring needs nx,ny >= 4 (got %llux%llu)",
                     (unsigned long long)nx, (unsigned long long)ny);
@@ -359,6 +373,8 @@ int lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doubl
             return fail(LBM_ERR_INVALID_ARGUMENT,
                         "slab rows that are not wall rows need a ghost row inside the array");
     }
+    if (g_layout == LBM_LAYOUT_AOS)
+        return aos_one_step<PULL, true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, stream);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
                ? sweep_lid_rows<float, PULL>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, st)
@@ -396,7 +412,7 @@ bool fused_supported(uint64_t nx)
     return nx >= 2;
 }
 
-template <typename T, int V, bool PUSH, bool LID>
+template <typename T, int V, bool PUSH, bool LID, bool AOS>
 int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
@@ -412,7 +428,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         // is as expensive as a full one (fp32 pull, GLUPS before -> after: 512^2 38 -> 46, 2048^2
         // 137 -> 174, 4096^2 180 -> 224, 8192^2 231 -> 253; 1024^2 stays at 107, launch-gap-bound).
         const uint64_t slots = 2048;   // 256 CUs x 4 SIMDs x 2 wavefronts
-        const uint64_t extra = PUSH ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
+        const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             uint64_t best = ~0ull;
             for (uint64_t s = 128; s >= 2; --s) {
@@ -435,7 +451,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const dim3 grid((unsigned)(nstrips * nsegs_grid)), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
-        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID>), grid, block, 0, stream, f, buf, g, om, df); \
+        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS>), grid, block, 0, stream, f, buf, g, om, df); \
         break;
     switch (k) {
         LBM_FUSED_CASE(1)
@@ -462,11 +478,19 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const T rho = (T)rho_, u = (T)u_;
     const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
-    if constexpr (V8 > 1) {
-        if (nx % V8 != 0 || nx < 2 * V8)
-            return launch_fused<T, 1, PUSH, LID>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+    const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8);
+    if (g_layout == LBM_LAYOUT_AOS) {
+        if constexpr (V8 > 1) {
+            if (narrow)
+                return launch_fused<T, 1, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+        }
+        return launch_fused<T, V8, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
     }
-    return launch_fused<T, V8, PUSH, LID>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+    if constexpr (V8 > 1) {
+        if (narrow)
+            return launch_fused<T, 1, PUSH, LID, false>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+    }
+    return launch_fused<T, V8, PUSH, LID, false>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
 }
 
 template <bool PULL>
@@ -479,7 +503,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
     const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
     // length the fused kernels cannot take
-    if (k == 1 && (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
+    if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
         return periodic_rows<PULL>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
     if (!wrap_y && y_lo < y_hi && (y_lo < (uint64_t)k || y_hi + (uint64_t)k > ny))
@@ -506,7 +530,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
     {
         const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
         const bool whole = y_lo == 0 && y_hi == ny && y_goff == 0 && ny_glob == ny;
-        if (k == 1 && (!supported || whole))
+        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || whole))
             return lid_rows<PULL>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
     }
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
@@ -534,6 +558,27 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
     return prec == LBM_F32
                ? sweep_fused<float, !PULL, true>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, k, st)
                : sweep_fused<double, !PULL, true>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, k, st);
+}
+
+// One-step entry points on [NY][NX][9] arrays run the multi-step kernels with one step.  Those
+// gather into the rows of the range; the one-step push sweeps scatter out of it, which is the same
+// thing only for a whole lattice.
+template <bool PULL, bool LID>
+int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, double rho_eq,
+                 double u_lid, uint64_t y_lo, uint64_t y_hi, int wrap_y, int64_t y_goff, uint64_t ny_glob,
+                 void *stream)
+{
+    if (nx < 2)
+        return fail(LBM_ERR_UNSUPPORTED, "[NY][NX][9] arrays need rows of at least two nodes (nx=%llu)",
+                    (unsigned long long)nx);
+    const bool whole = y_lo == 0 && y_hi == ny && (LID ? (y_goff == 0 && ny_glob == ny) : wrap_y != 0);
+    if (!PULL && !whole)
+        return fail(LBM_ERR_UNSUPPORTED,
+                    "push sweeps of a row range of [NY][NX][9] arrays: use the *_fused entry points with nsteps = 1");
+    hipStream_t st = (hipStream_t)stream;
+    return prec == LBM_F32
+               ? sweep_fused<float, !PULL, LID>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, wrap_y, y_goff, ny_glob, 1, st)
+               : sweep_fused<double, !PULL, LID>(f, buf, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, wrap_y, y_goff, ny_glob, 1, st);
 }
 
 // ---- initialisation --------------------------------------------------------------------
@@ -568,9 +613,15 @@ int fill_from_table(void *f_, uint64_t nx, uint64_t ny, uint64_t y_first, const 
     if (e == hipSuccess) {
         const unsigned block = pick_block(nx);
         const dim3 grid = make_grid(nx, block, rows);
-        LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_fill_rows<T, B>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
-                               (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table))
+        if (g_layout == LBM_LAYOUT_AOS) {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_fill_rows<T, B, true>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
+                                   (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table))
+        } else {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_fill_rows<T, B>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
+                                   (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table))
+        }
         e = hipGetLastError();
     }
     // the table (host vector and device copy) must outlive the kernel
@@ -619,9 +670,15 @@ int velocity_t(const void *f, void *out, uint64_t nx, uint64_t ny, uint64_t y_lo
     if (y_lo == y_hi) return LBM_OK;
     const unsigned block = pick_block(nx);
     const dim3 grid = make_grid(nx, block, y_hi - y_lo);
-    LBM_FOR_BLOCK(block,
-        hipLaunchKernelGGL((lbm::k_velocity<T, WHAT, B>), grid, dim3(B), 0, stream, (const T *)f, (T *)out,
-                           (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi))
+    if (g_layout == LBM_LAYOUT_AOS) {
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_velocity<T, WHAT, B, true>), grid, dim3(B), 0, stream, (const T *)f, (T *)out,
+                               (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi))
+    } else {
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_velocity<T, WHAT, B>), grid, dim3(B), 0, stream, (const T *)f, (T *)out,
+                               (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi))
+    }
     return launch_status("compute velocities");
 }
 
@@ -652,7 +709,13 @@ int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint6
         constexpr int B = 256;
         constexpr int V = vec_width<T>();
         const uint64_t rows = y_hi - y_lo;
-        if (nx % V == 0) {
+        if (g_layout == LBM_LAYOUT_AOS) {
+            uint64_t gx = (nx + B - 1) / B;
+            if (gx > 64) gx = 64;
+            uint64_t gy = rows < 1024 ? rows : 1024;
+            hipLaunchKernelGGL((lbm::k_max_speed<T, 1, B, true>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
+                               (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
+        } else if (nx % V == 0) {
             const uint64_t lanes = nx / V;
             uint64_t gx = (lanes + B - 1) / B;
             if (gx > 64) gx = 64;
@@ -692,6 +755,16 @@ const char *lbm_status_string(int status)
 const char *lbm_last_error(void) { return g_err; }
 
 int lbm_abi_version(void) { return 1; }
+
+int lbm_set_layout(int layout)
+{
+    if (layout != LBM_LAYOUT_SOA && layout != LBM_LAYOUT_AOS)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "unknown layout %d", layout);
+    g_layout = layout;
+    return LBM_OK;
+}
+
+int lbm_get_layout(void) { return g_layout; }
 
 int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu)
 {

@@ -853,7 +853,8 @@ k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t
 // Initialisation: broadcast a per-row table along x.  table is [9][rows]; array rows
 // [y_first, y_first+rows) are written.  Replaces the "initialize" / "initialize at rest"
 // dispatches (init.cpp:14-33, :37-48); the table holds what f_eq (init.cpp:57-84) returns.
-template <typename T, int BLOCK>
+// AOS: f is [NY][NX][9] (global.h:40) instead of [9][NY][NX].
+template <typename T, int BLOCK, bool AOS = false>
 __global__ void __launch_bounds__(BLOCK)
 k_fill_rows(T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_first, uint32_t rows,
             const T *__restrict__ table)
@@ -863,14 +864,17 @@ k_fill_rows(T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_first, uint3
     const size_t plane = (size_t)ny * nx;
     for (uint32_t r = blockIdx.y; r < rows; r += gridDim.y) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) rowp(f, plane, q, y_first + r, nx)[x] = table[q * rows + r];
+        for (int q = 0; q < 9; ++q) {
+            if (AOS) f[((size_t)(y_first + r) * nx + x) * 9 + q] = table[q * rows + r];
+            else     rowp(f, plane, q, y_first + r, nx)[x] = table[q * rows + r];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Output path.  WHAT: 0 = ux,uy planes (compute_velocities, io.cpp:136-174), 1 = |u| plane
 // (io.cpp:236-238).
-template <typename T, int WHAT, int BLOCK>
+template <typename T, int WHAT, int BLOCK, bool AOS = false>
 __global__ void __launch_bounds__(BLOCK)
 k_velocity(const T *__restrict__ f, T *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t y_lo,
            uint32_t y_hi)
@@ -882,7 +886,7 @@ k_velocity(const T *__restrict__ f, T *__restrict__ out, uint32_t nx, uint32_t n
     for (uint32_t y = y_lo + blockIdx.y; y < y_hi; y += gridDim.y) {
         T c[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
+        for (int q = 0; q < 9; ++q) c[q] = AOS ? f[((size_t)y * nx + x) * 9 + q] : rowp(f, plane, q, y, nx)[x];
         T ux, uy;
         node_velocity<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], ux, uy);
         const size_t o = (size_t)(y - y_lo) * nx + x;
@@ -904,7 +908,7 @@ __device__ __forceinline__ uint32_t speed_key(float u)
     return (u == u) ? (__float_as_uint(u) + 1u) : 0u;
 }
 
-template <typename T, int V, int BLOCK>
+template <typename T, int V, int BLOCK, bool AOS = false>
 __global__ void __launch_bounds__(BLOCK)
 k_max_speed(const T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_lo, uint32_t y_hi,
             uint32_t *__restrict__ key)
@@ -915,8 +919,14 @@ k_max_speed(const T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_lo, ui
     for (uint32_t y = y_lo + blockIdx.y; y < y_hi; y += gridDim.y) {
         for (uint32_t v = blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += gridDim.x * BLOCK) {
             T c[9][V];
+            if (AOS) {
+                static_assert(!AOS || V == 1, "array-of-structures rows are read one node per lane");
 #pragma unroll
-            for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, nx) + (size_t)v * V);
+                for (int q = 0; q < 9; ++q) c[q][0] = f[((size_t)y * nx + v) * 9 + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) load_a<T, V>(c[q], rowp(f, plane, q, y, nx) + (size_t)v * V);
+            }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 T ux, uy;

@@ -189,6 +189,38 @@ __device__ __forceinline__ void relax_row(T (&o)[9][V], const T (&c)[9][V], cons
     collide_nodes<T, V>(o, c, om);
 }
 
+// Array-of-structures lattices ([NY][NX][9], the reference's VIEW(view, x, y, q) = view(y, x, q) of
+// global.h:40): a lane's V nodes are 9 V consecutive values.  They move as nine V-wide accesses and
+// are sorted into populations in registers, so the lanes of one access sit 72 (36) bytes apart:
+// every 64-byte line is touched by several accesses of the same wavefront and filled or drained
+// in the cache, not in one instruction.
+template <typename T, int V>
+__device__ __forceinline__ void load_aos(T (&d)[9][V], const T *p)
+{
+    typedef typename VecTypes<T, V>::vec_t vec_t;
+    typedef typename VecTypes<T, V>::vec_a vec_a;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const vec_t v = *reinterpret_cast<const vec_a *>(p + k * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[(k * V + j) % 9][(k * V + j) / 9] = v[j];
+    }
+}
+// Plain stores: the nine accesses of a wavefront fill each line piecewise and must meet in the cache.
+template <typename T, int V>
+__device__ __forceinline__ void store_aos(T *p, const T (&d)[9][V])
+{
+    typedef typename VecTypes<T, V>::vec_t vec_t;
+    typedef typename VecTypes<T, V>::vec_a vec_a;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        vec_t v;
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = d[(k * V + j) % 9][(k * V + j) / 9];
+        *reinterpret_cast<vec_a *>(p + k * V) = v;
+    }
+}
+
 // One row of input as it sits in registers between its load and its use.
 template <typename T, int V>
 struct RowIn {
@@ -197,7 +229,9 @@ struct RowIn {
 };
 
 // K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
-template <typename T, int V, int K, bool PUSH, bool LID>
+// AOS: the arrays are [NY][NX][9].  The pull scheme then reads each row's own nine (post-collision)
+// populations like the push scheme does and streams every step in registers, the first one included.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
@@ -206,8 +240,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     constexpr int H = fused_halo_lanes<T, V, K>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
-    constexpr int NG = PUSH ? K : K - 1;     // streaming steps done in registers
-    constexpr int D = PUSH ? K : K - 1;      // rows between a segment's first row and the first row relaxed
+    constexpr bool OWN = PUSH || AOS;        // a row is loaded as its own nine populations
+    constexpr int NG = OWN ? K : K - 1;      // streaming steps done in registers
+    constexpr int D = NG;                    // rows between a segment's first row and the first row relaxed
     constexpr int NR = NG > 0 ? NG : 1;
 
     // Workgroups go to the 8 XCDs round-robin.  Plain mapping: strip fastest, so the two neighbours
@@ -290,7 +325,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     };
     auto load_row = [&](RowIn<T, V> &d) {
         const uint32_t y = y_m, yd = y_d, yu = y_u;
-        if (PUSH) {
+        if (AOS) {
+            load_aos<T, V>(d.v, f + ((size_t)y * g.nx + x0) * 9);
+        } else if (PUSH) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) load_a<T, V>(d.v[q], rowp(f, plane, q, y, g.nx) + x0);
         } else {
@@ -364,6 +401,11 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         T o[9][V];
         if (PUSH) {
             relax_row<T, V>(o, in.v, om);
+        } else if (AOS) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[q][e] = in.v[q][e];
         } else {
             T A[3][V], B[3][V], F[3][V], c[9][V];
 #pragma unroll
@@ -440,8 +482,12 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         }
         if (i >= (uint32_t)(D + NG) && store_lane) {
             const uint32_t yo = ys + i - (D + NG);
+            if (AOS) {
+                store_aos<T, V>(buf + ((size_t)yo * g.nx + x0) * 9, o);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, yo, g.nx) + x0, o[q]);
+                for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, yo, g.nx) + x0, o[q]);
+            }
         }
     };
 
@@ -473,11 +519,11 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
 // scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
 // every instantiation fits without spilling (157-256 VGPRs).
-template <typename T, int V, int K, bool PUSH, bool LID>
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
-    fused_body<T, V, K, PUSH, LID>(f, buf, g, om, df_lid);
+    fused_body<T, V, K, PUSH, LID, AOS>(f, buf, g, om, df_lid);
 }
 
 }  // namespace lbm

@@ -7,10 +7,14 @@ COALESCING=true, global.h:112, main.cpp:37-38), float32 or float64, contiguous, 
 Scalars that the reference passes as rank-0 device Views (DUI/DFL, global.h:121-147) are plain
 Python numbers here.  All calls are asynchronous on the tensor's current torch stream unless noted.
 
+`set_layout("aos")` switches every function to the reference's other layout, [NY, NX, 9]
+(COALESCING=false, global.h:40, main.cpp:34-35); the switch is process-wide, like the macro.
+
 There is no CPU path: a tensor that is not on a GPU is an error.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import torch
@@ -18,6 +22,38 @@ import torch
 from . import capi
 
 Q = 9
+SOA, AOS = "soa", "aos"
+_LAYOUT_CODES = {SOA: 0, AOS: 1}
+_layout = SOA
+
+
+def set_layout(layout: str) -> None:
+    """Layout of every population tensor from now on: "soa" = [9, NY, NX], "aos" = [NY, NX, 9]."""
+    global _layout
+    if layout not in _LAYOUT_CODES:
+        raise ValueError(f"layout must be 'soa' or 'aos', got {layout!r}")
+    capi.call("lbm_set_layout", _LAYOUT_CODES[layout])
+    _layout = layout
+
+
+def get_layout() -> str:
+    return _layout
+
+
+@contextlib.contextmanager
+def layout(name: str):
+    """`with ops.layout("aos"): ...` -- switch the process-wide layout for a block."""
+    before = _layout
+    set_layout(name)
+    try:
+        yield
+    finally:
+        set_layout(before)
+
+
+def population_shape(nx: int, ny: int):
+    """Shape of a population tensor of an nx x ny lattice in the current layout."""
+    return (ny, nx, Q) if _layout == AOS else (Q, ny, nx)
 
 
 def _prec(t: torch.Tensor) -> int:
@@ -34,6 +70,10 @@ def _check_f(f: torch.Tensor, name: str = "f"):
     if not f.is_cuda:
         raise RuntimeError(
             f"{name} lives on {f.device}: the lattice kernels are HIP-only (gfx950); there is no CPU path")
+    if _layout == AOS:
+        if f.dim() != 3 or f.shape[2] != Q or not f.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous [NY, NX, 9] tensor (layout 'aos'), got {tuple(f.shape)}")
+        return int(f.shape[1]), int(f.shape[0])
     if f.dim() != 3 or f.shape[0] != Q or not f.is_contiguous():
         raise ValueError(f"{name} must be a contiguous [9, NY, NX] tensor, got {tuple(f.shape)}")
     return int(f.shape[2]), int(f.shape[1])

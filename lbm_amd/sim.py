@@ -36,6 +36,10 @@ class Simulation:
     scene:  "shear" (periodic shear-wave decay, default) or "lid" (lid-driven cavity)
     scheme: "pull" or "push".  The reference's lid scene always pushes (main.cpp:72-74); here
             scheme="pull" with scene="lid" selects the pull form of the same boundary conditions.
+
+    The populations are allocated in the layout that is current when the object is made
+    (ops.set_layout: [9, NY, NX], or [NY, NX, 9] for the reference's COALESCING=false); the layout
+    must stay the same for as long as the object is used.
     """
 
     def __init__(self, nx: int, ny: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
@@ -51,7 +55,7 @@ class Simulation:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("Simulation needs a HIP device; there is no CPU path")
-        self.f = torch.empty((9, self.ny, self.nx), dtype=dtype, device=self.device)
+        self.f = torch.empty(ops.population_shape(self.nx, self.ny), dtype=dtype, device=self.device)
         self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
         self.t = 0
         self.launches = 0   # sweep launches so far (a launch advances 1..6 steps)

@@ -344,11 +344,11 @@ int main(int argc, char *argv[])
     std::cerr << "note: USE_MPI is set in src/macros.h; this driver runs one GPU per process and has no MPI path "
                  "(multi-GPU runs use the y-slab decomposition of the lbm_amd package)" << std::endl;
 #endif
-#if !COALESCING
-    std::cerr << "note: COALESCING=false (array-of-structures storage) is not available; running with the "
-                 "structure-of-arrays layout" << std::endl;
-#endif
     Run r;
+#if !COALESCING
+    // macros.h:7 / global.h:37-41: f and buf are [NY][NX][9] for the whole run
+    die_lbm(lbm_set_layout(LBM_LAYOUT_AOS), "set_layout");
+#endif
     try {
         r.o = parse_args(argc, argv);
         if (r.o.use_file) {

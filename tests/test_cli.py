@@ -18,10 +18,10 @@ BUILD = os.path.join(ROOT, "build")
 MAIN = os.path.join(BUILD, "main")
 
 
-def run_main(*args, check=True):
-    if not os.path.exists(MAIN):
-        pytest.fail("build/main is missing: run `python __graft_entry__.py` (cmake target `main`) first")
-    p = subprocess.run(["./main", *map(str, args)], cwd=BUILD, capture_output=True, text=True, timeout=600)
+def run_main(*args, check=True, exe="main"):
+    if not os.path.exists(os.path.join(BUILD, exe)):
+        pytest.fail(f"build/{exe} is missing: run `python __graft_entry__.py` (cmake target `main`) first")
+    p = subprocess.run([f"./{exe}", *map(str, args)], cwd=BUILD, capture_output=True, text=True, timeout=600)
     if check:
         assert p.returncode == 0, p.stderr
     return p
@@ -114,3 +114,18 @@ def test_ov_and_ovf_blocks(tmp_path):
     assert out.read_text() == want
     blocks = out.read_text().split("#")          # how the upstream scripts split frames
     assert len(blocks) == 7
+
+
+@pytest.mark.gpu
+def test_coalescing_false_build_prints_the_same(tmp_path):
+    """build/main_aos is the driver compiled with COALESCING=false (reference macros.h:7): arrays are
+    [NY][NX][9] throughout, the text that comes out is the same."""
+    for args in (("-nx", 96, "-ny", 40, "-w", 1.0, "-s", 301, "-of", 100, "-omv", "-push"),
+                 ("-nx", 130, "-ny", 70, "-w", 0.5, "-s", 1000, "-of", 250, "-omv"),
+                 ("-nx", 24, "-ny", 16, "-w", 1.7, "-s", 41, "-of", 20, "-ovf", "-ld"),
+                 ("-nx", 33, "-ny", 21, "-w", 1.2, "-s", 50, "-of", 25, "-ov", "-ld", "-push")):
+        a = run_main(*args)
+        b = run_main(*args, exe="main_aos")
+        assert a.stdout == b.stdout and a.stdout != "", args
+    p = run_main("-nx", 256, "-ny", 128, "-of", 0, "-s", 100, exe="main_aos")
+    check_stderr_contract(p.stderr, 256, 128, 100)
