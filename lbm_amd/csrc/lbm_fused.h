@@ -38,8 +38,15 @@
 // Lid-driven cavity: the gathers apply the half-way bounce-back map of pull-push.cpp:496-528 read
 // from the destination side (as lid_pull_node / lid_push_scatter do for one step): a population
 // whose upstream node lies behind a wall is the destination node's own opposite population, the
-// two that bounce off the lid carry -+ rho_eq*u_lid/6.
+// two that bounce off the lid carry -+ rho_eq*u_lid/6.  Only the two outermost strips hold wall
+// nodes and only a handful of iterations per cavity touch the bottom or the lid row, so each
+// iteration makes one wave-uniform test and runs either the periodic code or the code with the wall
+// cases in it (fused_body::iteration): testing inside every streaming step cost the fp64 sweeps
+// 12 % (16384^2, six steps: 132 -> 149 GLUPS with this and the DPP change below).
+//
+// Array-of-structures lattices ([NY][NX][9]): same kernels, other load / store code (load_aos).
 #pragma once
+#include <type_traits>
 #include "lbm_device.h"
 
 #pragma clang fp contract(off)
@@ -50,6 +57,10 @@
 #endif
 #ifndef LBM_FUSED_REG_RINGS_PUSH
 #define LBM_FUSED_REG_RINGS_PUSH 2
+#endif
+// Rows requested ahead of their use by the fp64 kernels (fp32: one).
+#ifndef LBM_FUSED_PREFETCH_F64
+#define LBM_FUSED_PREFETCH_F64 2
 #endif
 
 namespace lbm {
@@ -76,7 +87,9 @@ struct FusedGeom {
 };
 
 // Value held by the lane below / above in the wavefront (DPP wave_shr:1 / wave_shl:1).  Lane 0 /
-// lane 63 keep their own value; they are halo lanes whose result is never stored.
+// lane 63 have no such neighbour and receive zero (bound_ctrl); they are halo lanes whose result is
+// never stored.  Receiving zero rather than keeping the own value leaves the destination register
+// free to differ from the source, which spares a copy wherever the unshifted value stays live.
 template <typename T>
 __device__ __forceinline__ T from_lane_below(T v)
 {
@@ -84,7 +97,7 @@ __device__ __forceinline__ T from_lane_below(T v)
     union { T t; int w[N]; } a, b;
     a.t = v;
 #pragma unroll
-    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(a.w[k], a.w[k], 0x138, 0xf, 0xf, false);
+    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(0, a.w[k], 0x138, 0xf, 0xf, true);
     return b.t;
 }
 template <typename T>
@@ -94,7 +107,7 @@ __device__ __forceinline__ T from_lane_above(T v)
     union { T t; int w[N]; } a, b;
     a.t = v;
 #pragma unroll
-    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(a.w[k], a.w[k], 0x130, 0xf, 0xf, false);
+    for (int k = 0; k < N; ++k) b.w[k] = __builtin_amdgcn_update_dpp(0, a.w[k], 0x130, 0xf, 0xf, true);
     return b.t;
 }
 
@@ -118,6 +131,7 @@ __device__ __forceinline__ void arrive_from_right(T (&d)[V], const T (&s)[V])
 struct WallFlags {
     bool t, b;        // destination row is the lid row / the bottom row (wave-uniform)
     bool l, r;        // this lane's element 0 is the left wall node / element V-1 the right wall node
+    bool w;           // some lane of this wavefront has l or r set (wave-uniform)
 };
 
 // Streaming step towards one destination row, sources held in registers:
@@ -128,7 +142,9 @@ struct WallFlags {
 //   own7_l, own6_l: the destination row's populations 7 and 6 at the left wall node,
 //   own8_r, own5_r: its populations 8 and 5 at the right wall node (read by wall lanes only)
 // Result c[q] = population q arriving at the lane's V nodes.
-template <typename T, int V, bool LID, bool PUSH>
+// LID: a lid scene (its push form adds a zero lid term to two populations on every row);
+// WALLS: this call may meet a wall row or a wall node (otherwise fl is not looked at).
+template <typename T, int V, bool LID, bool PUSH, bool WALLS = LID>
 __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], const T (&B)[3][V],
                                            const T (&F)[3][V], const T (&TOP)[3][V], const T own7_l,
                                            const T own6_l, const T own8_r, const T own5_r,
@@ -149,13 +165,15 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
 #pragma unroll
         for (int i = 0; i < V; ++i) { s6[i] = s6[i] + T(0.); s5[i] = s5[i] - T(0.); }
     }
-    if (!LID || !(fl.t || fl.b)) {
+    if (!WALLS || !(fl.t || fl.b)) {
 #pragma unroll
         for (int i = 0; i < V; ++i) { c[5][i] = s5[i]; c[6][i] = s6[i]; c[4][i] = F[0][i]; c[7][i] = s7[i]; c[8][i] = s8[i]; }
     } else {
         // bottom wall: 2 <- 4 (already in A[0]), 5 <- 7, 6 <- 8 of the node itself (pull-push.cpp:520,
         // 523,526); lid: 4 <- 2, 7 <- 5 - df, 8 <- 6 + df of the node itself (:522,525,528).  Selects on
-        // wave-uniform flags keep every element in its register.
+        // wave-uniform flags keep every element in its register.  The empty asm statement keeps the
+        // compiler from folding this rare branch into selects that every row would execute.
+        asm volatile("; wall row");
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             c[5][i] = fl.b ? A[1][i] : s5[i];
@@ -165,7 +183,10 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
             c[8][i] = fl.t ? TOP[2][i] + df_lid : s8[i];
         }
     }
-    if (LID) {
+    // Only the two outermost strips hold wall nodes: everyone else branches around the patches
+    // (in fp64 they are a sixth of a node's instructions).
+    if (WALLS && fl.w) {
+        asm volatile("; wall strip");
         const T z = T(0.);
         if (fl.l) {   // left wall: 1 <- 3, 5 <- 7, 8 <- 6 (+ zero lid term) of the node itself
             c[1][0] = B[2][0];
@@ -225,7 +246,7 @@ __device__ __forceinline__ void store_aos(T *p, const T (&d)[9][V])
 template <typename T, int V>
 struct RowIn {
     T v[9][V];      // pull: slots by destination population; push: the row's nine populations
-    T w[4];         // lid pull: own 7, own 6 at the left wall node; own 8, own 5 at the right wall node
+    T w[2];         // lid pull, outermost strips: the row's own 6 at x = 0 and own 5 at x = nx-1
 };
 
 // K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
@@ -279,6 +300,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     fl0.r = LID && x0 + V == g.nx;
     // does any lane of this wavefront sit at a side wall (wave-uniform)?
     const bool wall_wave = LID && __ballot(fl0.l || fl0.r) != 0;
+    fl0.w = wall_wave;
 
     const uint32_t ys = g.y_lo + seg * g.seg_rows;
     const uint32_t ye = min(ys + g.seg_rows, g.y_hi);
@@ -296,22 +318,13 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         }
         return (uint32_t)R;
     };
-    auto wall_rows = [&](int64_t R, bool &t, bool &b) {
-        if (LID) {
-            const int64_t gy = R + g.y_goff;
-            b = gy == 0;
-            t = gy == (int64_t)g.ny_glob - 1;
-        } else {
-            t = false; b = false;
-        }
-    };
-
     // Sliding window over the rows the next load needs, advanced incrementally (a 64-bit modulo per
     // row index would cost more scalar instructions than the relaxation costs vector ones): Rn is
     // the lattice row relaxed first in the iteration being loaded, y_d / y_m / y_u the array rows of
     // Rn-1, Rn, Rn+1.  Loads are requested in iteration order.
     int32_t Rn = (int32_t)ys - D;
     uint32_t y_d = row_index((int64_t)Rn - 1), y_m = row_index((int64_t)Rn), y_u = row_index((int64_t)Rn + 1);
+    auto sat32 = [](int64_t v) -> int32_t { return v > INT32_MAX ? INT32_MAX : (v < INT32_MIN ? INT32_MIN : (int32_t)v); };
     auto advance_rows = [&]() {
         ++Rn;
         y_d = y_m;
@@ -331,32 +344,22 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 #pragma unroll
             for (int q = 0; q < 9; ++q) load_a<T, V>(d.v[q], rowp(f, plane, q, y, g.nx) + x0);
         } else {
-            bool t, b;
-            wall_rows(Rn, t, b);
-            // pull-push.cpp:13-21; at the lid / the bottom wall the node's own populations instead
-            const T *p7 = t ? rowp(f, plane, 5, y, g.nx) : rowp(f, plane, 7, yu, g.nx);
-            const T *p4 = t ? rowp(f, plane, 2, y, g.nx) : rowp(f, plane, 4, yu, g.nx);
-            const T *p8 = t ? rowp(f, plane, 6, y, g.nx) : rowp(f, plane, 8, yu, g.nx);
-            const T *p6 = b ? rowp(f, plane, 8, y, g.nx) : rowp(f, plane, 6, yd, g.nx);
-            const T *p2 = b ? rowp(f, plane, 4, y, g.nx) : rowp(f, plane, 2, yd, g.nx);
-            const T *p5 = b ? rowp(f, plane, 7, y, g.nx) : rowp(f, plane, 5, yd, g.nx);
-            load_a<T, V>(d.v[7], p7 + x0);
-            load_a<T, V>(d.v[4], p4 + x0);
-            load_a<T, V>(d.v[8], p8 + x0);
+            // pull-push.cpp:13-21.  Lid scenes load the wall rows like any other row (the row
+            // beyond the wall is the wall row itself, clamped) and fetch what the walls reflect
+            // when the row is used (iteration_of): tests here would cost every row scalar work.
+            load_a<T, V>(d.v[7], rowp(f, plane, 7, yu, g.nx) + x0);
+            load_a<T, V>(d.v[4], rowp(f, plane, 4, yu, g.nx) + x0);
+            load_a<T, V>(d.v[8], rowp(f, plane, 8, yu, g.nx) + x0);
             load_a<T, V>(d.v[3], rowp(f, plane, 3, y, g.nx) + x0);
             load_a<T, V>(d.v[0], rowp(f, plane, 0, y, g.nx) + x0);
             load_a<T, V>(d.v[1], rowp(f, plane, 1, y, g.nx) + x0);
-            load_a<T, V>(d.v[6], p6 + x0);
-            load_a<T, V>(d.v[2], p2 + x0);
-            load_a<T, V>(d.v[5], p5 + x0);
+            load_a<T, V>(d.v[6], rowp(f, plane, 6, yd, g.nx) + x0);
+            load_a<T, V>(d.v[2], rowp(f, plane, 2, yd, g.nx) + x0);
+            load_a<T, V>(d.v[5], rowp(f, plane, 5, yd, g.nx) + x0);
             if (LID && wall_wave) {
-                // the row's own populations at the wall nodes, for the wall lanes: element 0 of a
-                // left-wall lane is x = 0, element V-1 of a right-wall lane x = nx-1.  Per-lane
-                // addresses keep these on the vector memory path next to the nine row loads.
-                d.w[0] = rowp(f, plane, 7, y, g.nx)[x0];
-                d.w[1] = rowp(f, plane, 6, y, g.nx)[x0];
-                d.w[2] = rowp(f, plane, 8, y, g.nx)[x0 + V - 1];
-                d.w[3] = rowp(f, plane, 5, y, g.nx)[x0 + V - 1];
+                // per-lane addresses keep these on the vector memory path next to the row loads
+                d.w[0] = rowp(f, plane, 6, y, g.nx)[x0];
+                d.w[1] = rowp(f, plane, 5, y, g.nx)[x0 + V - 1];
             }
         }
         advance_rows();
@@ -396,8 +399,28 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         ring_lds[ring][slot][threadIdx.x] = v;
     };
 
-    auto iteration = [&](const RowIn<T, V> &in, uint32_t i) {
-        const int64_t Rc = (int64_t)ys - D + (int64_t)i;
+    // Lid scenes, pull, wavefronts of the two outermost strips: the side walls reflect the wall nodes'
+    // own 7, 6 (left wall; element 0 of a left-wall lane is x = 0) and 8, 5 (right wall; element V-1
+    // of a right-wall lane is x = nx-1) back into the row.  Own 6 and 5 are loaded with the row
+    // (RowIn::w).  Own 7 and 8 of row R are what row R-1 pulls from above, so they are carried over
+    // from the previous iteration's input; the first iteration loads them.
+    T own7_left = T(0), own8_right = T(0);
+    if (LID && !OWN && wall_wave) {
+        const uint32_t y = row_index((int64_t)ys - D);
+        own7_left = rowp(f, plane, 7, y, g.nx)[x0];
+        own8_right = rowp(f, plane, 8, y, g.nx)[x0 + V - 1];
+    }
+
+    // Iteration i relaxes row Rc = ys - D + i first and then takes the rows Rc - 1, Rc - 2, ... one
+    // streaming step further each.  to_bottom / to_lid: rows between Rc and the bottom / the lid row.
+    // `walls` is a compile-time flag of the call: false = no wall row and no wall node takes part in
+    // this iteration, and the code is that of the periodic sweeps.
+    auto iteration_of = [&](const RowIn<T, V> &in, uint32_t i, int32_t to_bottom, int32_t to_lid, auto walls) {
+        constexpr bool WALLS = decltype(walls)::value;
+        auto wall_rows_below = [&](int k, bool &t, bool &b) {   // row Rc - k
+            b = WALLS && to_bottom == k;
+            t = WALLS && to_lid == k;
+        };
         T o[9][V];
         if (PUSH) {
             relax_row<T, V>(o, in.v, om);
@@ -415,22 +438,43 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                 F[0][e] = in.v[4][e]; F[1][e] = in.v[7][e]; F[2][e] = in.v[8][e];
             }
             WallFlags fl = fl0;
-            wall_rows(Rc, fl.t, fl.b);
-            // at the lid the F slots were loaded with the row's own (2,5,6)
-            gather_row<T, V, LID, false>(c, A, B, F, F, in.w[0], in.w[1], in.w[2], in.w[3], fl, df_lid);
+            wall_rows_below(0, fl.t, fl.b);
+            // What the lid and the bottom wall reflect comes from row Rc itself and is loaded here,
+            // when it is needed: only the iterations at those walls wait for it.  At the lid the
+            // row's own (2,5,6) stand in for what would arrive from above, at the bottom wall its
+            // own (4,7,8) for what would arrive from below.
+            T w7 = T(0), w6 = T(0), w8 = T(0), w5 = T(0);
+            if (WALLS) {
+                const uint32_t y = row_index((int64_t)ys - D + (int64_t)i);
+                if (fl.t) {
+                    load_a<T, V>(F[0], rowp(f, plane, 2, y, g.nx) + x0);
+                    load_a<T, V>(F[1], rowp(f, plane, 5, y, g.nx) + x0);
+                    load_a<T, V>(F[2], rowp(f, plane, 6, y, g.nx) + x0);
+                }
+                if (fl.b) {
+                    load_a<T, V>(A[0], rowp(f, plane, 4, y, g.nx) + x0);
+                    load_a<T, V>(A[1], rowp(f, plane, 7, y, g.nx) + x0);
+                    load_a<T, V>(A[2], rowp(f, plane, 8, y, g.nx) + x0);
+                }
+                w7 = own7_left; w6 = in.w[0]; w8 = own8_right; w5 = in.w[1];
+                // what this row pulls from above is the next row's own
+                own7_left = in.v[7][0];
+                own8_right = in.v[8][V - 1];
+            }
+            gather_row<T, V, LID, false, WALLS>(c, A, B, F, F, w7, w6, w8, w5, fl, df_lid);
             relax_row<T, V>(o, c, om);
         }
 #pragma unroll
         for (int s = 0; s < NG; ++s) {
-            const int64_t r = Rc - s;          // row held in o; destination row r - 1
+            // row Rc - s is held in o; the destination row is the one below it
             T F[3][V], c[9][V];
 #pragma unroll
             for (int e = 0; e < V; ++e) { F[0][e] = o[4][e]; F[1][e] = o[7][e]; F[2][e] = o[8][e]; }
             WallFlags fl = fl0;
-            wall_rows(r - 1, fl.t, fl.b);
-            // what the next rows need of row r
+            wall_rows_below(s + 1, fl.t, fl.b);
+            // what the next rows need of row Rc - s
             bool rt, rb;
-            wall_rows(r, rt, rb);
+            wall_rows_below(s, rt, rb);
             if (s < NLDS) {
                 // keep the LDS reads of this step from being hoisted above the previous step's
                 // arithmetic: hoisted, every LDS ring costs 18 more live registers and the kernel spills
@@ -443,9 +487,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                     lds_get(C[k], s, (par ^ 1u) * 3 + k);
                     lds_get(B[k], s, 6 + k);
                 }
-                gather_row<T, V, LID, PUSH>(c, A, B, F, C, ring7[s], C[2][0], ring8[s], C[1][V - 1], fl, df_lid);
-                if (LID && rb) {
-                    // row r is the bottom row: next iteration it bounces its own (4,7,8)
+                gather_row<T, V, LID, PUSH, WALLS>(c, A, B, F, C, ring7[s], C[2][0], ring8[s], C[1][V - 1], fl, df_lid);
+                if (WALLS && rb) {
+                    // this is the bottom row: next iteration it bounces its own (4,7,8)
                     lds_put(s, (par ^ 1u) * 3 + 0, o[4]); lds_put(s, (par ^ 1u) * 3 + 1, o[7]); lds_put(s, (par ^ 1u) * 3 + 2, o[8]);
                 }
                 lds_put(s, par * 3 + 0, o[2]); lds_put(s, par * 3 + 1, o[5]); lds_put(s, par * 3 + 2, o[6]);
@@ -453,10 +497,11 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
             } else {
                 constexpr int kNone = 0;
                 const int q = s >= NLDS ? s - NLDS : kNone;   // register ring of this step
-                gather_row<T, V, LID, PUSH>(c, ringA[q], ringB[q], F, ringC[q], ring7[s], ringC[q][2][0],
+                gather_row<T, V, LID, PUSH, WALLS>(c, ringA[q], ringB[q], F, ringC[q], ring7[s], ringC[q][2][0],
                                             ring8[s], ringC[q][1][V - 1], fl, df_lid);
-                if (LID && rb) {
-                    // row r is the bottom row: next iteration it bounces its own (4,7,8)
+                if (WALLS && rb) {
+                    // this is the bottom row: next iteration it bounces its own (4,7,8)
+                    asm volatile("; bottom row");   // a branch, not selects on every row
 #pragma unroll
                     for (int e = 0; e < V; ++e) { ringA[q][0][e] = o[4][e]; ringA[q][1][e] = o[7][e]; ringA[q][2][e] = o[8][e]; }
                 } else {
@@ -469,8 +514,10 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                     ringC[q][0][e] = o[2][e]; ringC[q][1][e] = o[5][e]; ringC[q][2][e] = o[6][e];
                 }
             }
-            ring7[s] = o[7][0];
-            ring8[s] = o[8][V - 1];
+            if (WALLS) {   // read by wall lanes only, and a wavefront with wall lanes always comes here
+                ring7[s] = o[7][0];
+                ring8[s] = o[8][V - 1];
+            }
             if (PUSH && s == NG - 1) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q)
@@ -490,17 +537,33 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
             }
         }
     };
+    // Lid scenes: one wave-uniform test per iteration picks the code.  Walls take part if the
+    // wavefront holds wall nodes, or if one of the rows Rc .. Rc - NG that this iteration gathers
+    // into or keeps for the next one is the bottom or the lid row.  Everything else -- all but two
+    // strips and a few iterations of the first and last segments -- runs the periodic code: as
+    // separate tests inside every streaming step the wall cases cost the fp64 lid sweeps 8-15 %.
+    auto iteration = [&](const RowIn<T, V> &in, uint32_t i) {
+        if (LID) {
+            // rows between row Rc and the bottom row / the lid row, saturated to 32 bits
+            const int64_t gy = (int64_t)ys - D + (int64_t)i + g.y_goff;
+            const int32_t to_bottom = sat32(gy), to_lid = sat32(gy - ((int64_t)g.ny_glob - 1));
+            if (wall_wave || (uint32_t)to_bottom <= (uint32_t)NG || (uint32_t)to_lid <= (uint32_t)NG)
+                iteration_of(in, i, to_bottom, to_lid, std::true_type());
+            else
+                iteration_of(in, i, 0, 0, std::false_type());
+        } else {
+            iteration_of(in, i, 0, 0, std::false_type());
+        }
+    };
 
     // Rows are requested PF iterations ahead of their use; PF + 1 register buffers rotate through
     // a loop unrolled by PF + 1.  One iteration of fp64 work (~0.8 us) is shorter than the memory
     // latency under load, so fp64 looks two rows ahead (37 % of its wave time sat in s_waitcnt with
     // one); fp32 has no registers to spare for that under the 256-register cap.
-    constexpr int PF = (sizeof(T) == 8 && V == 1) ? 2 : 1;
+    constexpr int PF = (sizeof(T) == 8 && V == 1) ? LBM_FUSED_PREFETCH_F64 : 1;
     RowIn<T, V> in[PF + 1];
 #pragma unroll
-    for (int j = 0; j <= PF; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) in[j].w[k] = T(0);
+    for (int j = 0; j <= PF; ++j) { in[j].w[0] = T(0); in[j].w[1] = T(0); }
 #pragma unroll
     for (int j = 0; j < PF; ++j)
         if ((uint32_t)j < iters) load_row(in[j]);
@@ -518,7 +581,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
 // scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
-// every instantiation fits without spilling (157-256 VGPRs).
+// every instantiation fits without spilling (at most 239 VGPRs).
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
