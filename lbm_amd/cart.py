@@ -1,0 +1,250 @@
+"""2-D Cartesian decomposition of the periodic shear-wave lattice over ranks (torch.distributed).
+
+The reference's MPI path (src/main.cpp:92-401): ranks form a periodic dims[0] x dims[1] grid, every
+rank owns an nx x ny block of the lattice inside a local array with a halo of one node on every
+side -- [9][ny+2][nx+2], owned nodes at 1..ny, 1..nx -- and one time step is
+
+    exchange halos  ||  pull_periodic_inner on the nodes that touch no halo (main.cpp:321)
+    pull_periodic_outer on the ring of owned nodes next to the halo (main.cpp:388), swap.
+
+What differs from the reference, on purpose:
+  * the exchange is device to device (RCCL send/recv when the backend is "nccl"), not staged
+    through host mirrors (main.cpp:275-283, :330-338);
+  * two phases instead of eight messages: columns first, then rows *including* the halo columns,
+    so the four corner values (main.cpp:262-273, :363-374) ride along with the rows -- four
+    messages per step and rank, each to a direct neighbour;
+  * a halo column gets the populations that move in +x / -x and a halo row those that move in
+    +y / -y, which is all the pull sweep reads there (the reference sends the same three per side);
+  * blocks are initialised from the global row index; the reference's own offset
+    (main.cpp:144) is wrong for ranks that do not sit in the bottom row of the grid.
+
+Only the pull scheme of the periodic scene runs here, as in the reference, whose lid-driven
+cavity refuses to run under MPI (main.cpp:317-319).  For one node of GPUs the y-slab path
+(lbm_amd.slab) is the fast one -- it keeps rows whole, so its sweeps are the vectorised and
+multi-step kernels; this module exists for lattices cut in both directions and is bit-identical
+to the single-device result.
+
+Kernels are reached through a small backend object so that the schedule can be exercised on CPU
+ranks in tests; the default backend is the HIP operator layer and refuses CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .slab import _edge_stream
+
+# populations that move in +x, -x, +y, -y (D2Q9 numbering of global.h:86-93)
+RIGHT_MOVERS = (1, 5, 8)
+LEFT_MOVERS = (3, 6, 7)
+UP_MOVERS = (2, 5, 6)
+DOWN_MOVERS = (4, 7, 8)
+
+
+def dims_create(world: int) -> Tuple[int, int]:
+    """The most nearly square dims[0] >= dims[1] with dims[0] * dims[1] == world (what
+    MPI_Dims_create(size, 2, dims) returns, main.cpp:103)."""
+    if world < 1:
+        raise ValueError("world size must be positive")
+    d1 = int(world ** 0.5)
+    while world % d1:
+        d1 -= 1
+    return world // d1, d1
+
+
+def block_extent(n_glob: int, parts: int, coord: int) -> Tuple[int, int]:
+    """(nodes owned, global index of the first owned node) along one axis: remainder nodes go to
+    the lowest coordinates (main.cpp:131-141)."""
+    base, rem = divmod(n_glob, parts)
+    return base + (1 if coord < rem else 0), coord * base + min(coord, rem)
+
+
+class HipCartBackend:
+    """Block kernels on the HIP operator layer (lbm_amd.ops)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def init_shearwave(self, f, rho, u, y_below, y_glob):
+        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=1)
+
+    def pull_inner(self, f, buf, om, LX, LY, HX, HY):
+        self.ops.pull_periodic_inner(f, buf, om, LX, LY, HX, HY)
+
+    def pull_outer(self, f, buf, om):
+        self.ops.pull_periodic_outer(f, buf, om, f.shape[2], f.shape[1])
+
+    def compute_velocities(self, vel, f, y_lo, y_hi):
+        self.ops.compute_velocities(vel, f, 0, y_lo, f.shape[2], y_hi)
+
+
+class CartSimulation:
+    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull scheme."""
+
+    def __init__(self, nx_glob: int, ny_glob: int, dtype: torch.dtype = torch.float32, omega: float = 0.5,
+                 rho: float = 1.0, u: float = 0.1, device="cuda:0", backend=None,
+                 dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.backend = backend if backend is not None else HipCartBackend()
+        if backend is None and not self.cuda:
+            raise RuntimeError("CartSimulation needs a HIP device; there is no CPU path")
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            self.stream_ordered = self.cuda and dist.get_backend(group) == "nccl"
+        else:
+            self.world, self.rank, self.stream_ordered = 1, 0, False
+        self.dims = tuple(int(d) for d in dims) if dims is not None else dims_create(self.world)
+        if len(self.dims) != 2 or self.dims[0] * self.dims[1] != self.world:
+            raise ValueError(f"dims {self.dims} do not multiply to the world size {self.world}")
+        # row-major rank <-> coordinates, as MPI_Cart_create numbers them (main.cpp:104-106)
+        self.coords = (self.rank // self.dims[1], self.rank % self.dims[1])
+        self.nx_glob, self.ny_glob = int(nx_glob), int(ny_glob)
+        self.nx, self.x_before = block_extent(self.nx_glob, self.dims[0], self.coords[0])
+        self.ny, self.y_below = block_extent(self.ny_glob, self.dims[1], self.coords[1])
+        # the smallest block of the grid, so that every rank raises or none does
+        if self.nx_glob // self.dims[0] < 2 or self.ny_glob // self.dims[1] < 2:
+            raise ValueError(f"a {self.nx_glob} x {self.ny_glob} lattice on a {self.dims[0]} x {self.dims[1]} grid of "
+                             "ranks leaves blocks of fewer than 2 x 2 nodes")
+        self.omega = float(omega)
+        self.t = 0
+        self.f = torch.zeros((9, self.ny + 2, self.nx + 2), dtype=dtype, device=self.device)
+        self.buf = torch.zeros_like(self.f)
+        self.backend.init_shearwave(self.f, float(rho), float(u), self.y_below, self.ny_glob)
+        self._idx = {name: torch.tensor(ch, dtype=torch.long, device=self.device)
+                     for name, ch in (("R", RIGHT_MOVERS), ("L", LEFT_MOVERS), ("U", UP_MOVERS), ("D", DOWN_MOVERS))}
+        self._col = [torch.empty((3, self.ny), dtype=dtype, device=self.device) for _ in range(2)]
+        self._row = [torch.empty((3, self.nx + 2), dtype=dtype, device=self.device) for _ in range(2)]
+        self._vel: Optional[torch.Tensor] = None
+        # a second stream only where the exchange is stream-ordered (RCCL, or copies within the
+        # rank); under the rehearsal transport the exchange blocks the host anyway
+        self.overlap = bool(overlap) and self.cuda and (self.world == 1 or self.stream_ordered)
+        # the device's one communication stream, shared with the y-slab path: see slab._edge_stream
+        # for why every object must not take a fresh stream
+        self._comm = _edge_stream(self.device) if self.overlap else None
+
+    # ---- neighbours ---------------------------------------------------------------------------
+    def _rank_at(self, cx: int, cy: int) -> int:
+        return (cx % self.dims[0]) * self.dims[1] + (cy % self.dims[1])
+
+    def _peer(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def _swap(self, send_hi, send_lo, recv_lo, recv_hi, hi_rank: int, lo_rank: int) -> None:
+        """send_hi goes to the neighbour at the higher coordinate and arrives in its recv_lo;
+        send_lo goes to the lower neighbour and arrives in its recv_hi."""
+        if hi_rank == self.rank:            # one rank along this axis: the lattice wraps onto itself
+            recv_lo.copy_(send_hi)
+            recv_hi.copy_(send_lo)
+            return
+        # A transport that is not stream-ordered (gloo) gets host tensors: what it does with device
+        # pointers is its own business, and a receive that lands in device memory behind the GPU's
+        # caches was seen to leave the next kernel with the previous step's values now and then.
+        staged = self.cuda and not self.stream_ordered
+        if staged:
+            out_hi, out_lo = send_hi.cpu(), send_lo.cpu()        # synchronous copies
+            in_lo, in_hi = torch.empty_like(out_hi), torch.empty_like(out_lo)
+        else:
+            out_hi, out_lo, in_lo, in_hi = send_hi, send_lo, recv_lo, recv_hi
+        # same order on every rank: with two ranks along an axis both messages go to one peer and
+        # are matched in the order they were posted
+        ops = [dist.P2POp(dist.isend, out_hi, self._peer(hi_rank), self.group),
+               dist.P2POp(dist.isend, out_lo, self._peer(lo_rank), self.group),
+               dist.P2POp(dist.irecv, in_lo, self._peer(lo_rank), self.group),
+               dist.P2POp(dist.irecv, in_hi, self._peer(hi_rank), self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if staged:
+            recv_lo.copy_(in_lo)
+            recv_hi.copy_(in_hi)
+
+    def _exchange(self) -> None:
+        f, nx, ny = self.f, self.nx, self.ny
+        cx, cy = self.coords
+        R, L, U, D = (self._idx[k] for k in "RLUD")
+        # columns: what moves in +x leaves through the last owned column, what moves in -x through
+        # the first (main.cpp:250-261 packs the same populations)
+        to_right = f[R, 1:ny + 1, nx]
+        to_left = f[L, 1:ny + 1, 1]
+        self._swap(to_right, to_left, self._col[0], self._col[1], self._rank_at(cx + 1, cy), self._rank_at(cx - 1, cy))
+        f[R, 1:ny + 1, 0] = self._col[0]
+        f[L, 1:ny + 1, nx + 1] = self._col[1]
+        # rows, halo columns included: the corner nodes' diagonal movers travel with them
+        to_up = f[U, ny, :]
+        to_down = f[D, 1, :]
+        self._swap(to_up, to_down, self._row[0], self._row[1], self._rank_at(cx, cy + 1), self._rank_at(cx, cy - 1))
+        f[U, 0, :] = self._row[0]
+        f[D, ny + 1, :] = self._row[1]
+
+    # ---- one time step (main.cpp:217-398) ------------------------------------------------------
+    def step(self, nsteps: int = 1) -> None:
+        for _ in range(int(nsteps)):
+            NX, NY = self.nx + 2, self.ny + 2
+            if self.overlap:
+                # the exchange waits for the previous step only, not for the inner sweep launched
+                # next to it
+                main = torch.cuda.current_stream(self.device)
+                self._comm.wait_stream(main)
+                self.backend.pull_inner(self.f, self.buf, self.omega, 2, 2, NX - 2, NY - 2)
+                with torch.cuda.stream(self._comm):
+                    self._exchange()
+                main.wait_stream(self._comm)
+            else:
+                self._exchange()
+                self.backend.pull_inner(self.f, self.buf, self.omega, 2, 2, NX - 2, NY - 2)
+            self.backend.pull_outer(self.f, self.buf, self.omega)
+            self.f, self.buf = self.buf, self.f
+            self.t += 1
+
+    # ---- outputs --------------------------------------------------------------------------------
+    def velocities(self) -> torch.Tensor:
+        """ux, uy of the owned nodes: [2, ny, nx]."""
+        if self._vel is None:
+            self._vel = torch.empty((2, self.ny, self.nx + 2), dtype=self.f.dtype, device=self.device)
+        self.backend.compute_velocities(self._vel, self.f, 1, self.ny + 1)
+        return self._vel[:, :, 1:self.nx + 1]
+
+    def max_velocity(self) -> float:
+        """Global max |u| (io.cpp:184-216: float square root, NaN never wins, MPI_Reduce(MAX))."""
+        v = self.velocities()
+        speed = torch.sqrt((v[0] * v[0] + v[1] * v[1]).to(torch.float32))
+        speed = torch.where(torch.isnan(speed), torch.full_like(speed, -1e30), speed)
+        m = speed.max().reshape(1)
+        if self.world > 1:
+            if self.cuda and not self.stream_ordered:
+                m = m.cpu()
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        return float(m.item())
+
+    def interior(self) -> torch.Tensor:
+        """The owned nodes without the halo: [9, ny, nx] (a view)."""
+        return self.f[:, 1:self.ny + 1, 1:self.nx + 1]
+
+    def gather_populations(self) -> Optional[torch.Tensor]:
+        """Rank 0 gets the global [9, NY, NX] populations (for tests / small outputs)."""
+        mine = self.interior().contiguous()
+        if self.world == 1:
+            return mine
+        staged = self.cuda and not self.stream_ordered     # see _swap
+        if self.rank != 0:
+            dist.send(mine.cpu() if staged else mine, self._peer(0), group=self.group)
+            return None
+        out = torch.empty((9, self.ny_glob, self.nx_glob), dtype=mine.dtype, device=self.device)
+        for r in range(self.world):
+            cx, cy = r // self.dims[1], r % self.dims[1]
+            nx, x0 = block_extent(self.nx_glob, self.dims[0], cx)
+            ny, y0 = block_extent(self.ny_glob, self.dims[1], cy)
+            part = mine
+            if r != 0:
+                part = torch.empty((9, ny, nx), dtype=mine.dtype, device="cpu" if staged else self.device)
+                dist.recv(part, self._peer(r), group=self.group)
+            out[:, y0:y0 + ny, x0:x0 + nx] = part.to(self.device)
+        return out
+
+    def synchronize(self) -> None:
+        if self.cuda:
+            torch.cuda.synchronize(self.device)

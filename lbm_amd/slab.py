@@ -33,7 +33,7 @@ on CPU ranks in tests; the default backend is the HIP operator layer and refuses
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -265,24 +265,20 @@ class SlabSimulation:
                 # send down is what the lower rank receives "from above", so sends go [down, up] and
                 # receives [from above, from below]; with two ranks both neighbours are the same
                 # peer and this order is what keeps the two directions apart.
-                p2p: List[dist.P2POp] = []
+                p2p = []
                 if self.lower is not None:
                     for q in DOWN_CHANNELS:
-                        p2p.append(dist.P2POp(dist.isend, a[q, s_dn, xs(q)], self._peer(self.lower), self.group, tag=q))
+                        p2p.append(("send", a[q, s_dn, xs(q)], self.lower, q))
                 if self.upper is not None:
                     for q in UP_CHANNELS:
-                        p2p.append(dist.P2POp(dist.isend, a[q, s_up, xs(q)], self._peer(self.upper), self.group, tag=q))
+                        p2p.append(("send", a[q, s_up, xs(q)], self.upper, q))
                 if self.upper is not None:
                     for q in DOWN_CHANNELS:
-                        p2p.append(dist.P2POp(dist.irecv, a[q, r_up, xs(q)], self._peer(self.upper), self.group, tag=q))
+                        p2p.append(("recv", a[q, r_up, xs(q)], self.upper, q))
                 if self.lower is not None:
                     for q in UP_CHANNELS:
-                        p2p.append(dist.P2POp(dist.irecv, a[q, r_dn, xs(q)], self._peer(self.lower), self.group, tag=q))
-                if p2p:
-                    if not self.stream_ordered:
-                        (self.comm_stream if self.overlap else self.compute_stream).synchronize()
-                    for req in dist.batch_isend_irecv(p2p):
-                        req.wait()
+                        p2p.append(("recv", a[q, r_dn, xs(q)], self.lower, q))
+                self._transfer(p2p)
             if self.cuda and self.overlap:
                 self._halo_done.record(self.comm_stream)
         self._halo_pending = True
@@ -306,22 +302,18 @@ class SlabSimulation:
                     self._stage = torch.empty((4, 9, G, self.nx), dtype=a.dtype, device=a.device)
                 send_lo, send_hi, recv_lo, recv_hi = self._stage
                 # same pairing rule as _exchange: sends [down, up], receives [from above, from below]
-                p2p: List[dist.P2POp] = []
+                p2p = []
                 if self.lower is not None:
                     send_lo.copy_(a[:, lo_own])
-                    p2p.append(dist.P2POp(dist.isend, send_lo, self._peer(self.lower), self.group))
+                    p2p.append(("send", send_lo, self.lower, 0))
                 if self.upper is not None:
                     send_hi.copy_(a[:, hi_own])
-                    p2p.append(dist.P2POp(dist.isend, send_hi, self._peer(self.upper), self.group))
+                    p2p.append(("send", send_hi, self.upper, 0))
                 if self.upper is not None:
-                    p2p.append(dist.P2POp(dist.irecv, recv_hi, self._peer(self.upper), self.group))
+                    p2p.append(("recv", recv_hi, self.upper, 0))
                 if self.lower is not None:
-                    p2p.append(dist.P2POp(dist.irecv, recv_lo, self._peer(self.lower), self.group))
-                if p2p:
-                    if not self.stream_ordered:
-                        (self.comm_stream if self.overlap else self.compute_stream).synchronize()
-                    for req in dist.batch_isend_irecv(p2p):
-                        req.wait()
+                    p2p.append(("recv", recv_lo, self.lower, 0))
+                self._transfer(p2p)
                 if self.upper is not None:
                     a[:, hi_ghost].copy_(recv_hi)
                 if self.lower is not None:
@@ -329,6 +321,34 @@ class SlabSimulation:
             if self.cuda and self.overlap:
                 self._halo_done.record(self.comm_stream)
         self._halo_pending = True
+
+    def _transfer(self, items) -> None:
+        """One grouped send/recv; items are ("send" | "recv", tensor, group rank of the peer, tag)
+        in posting order.  A transport that is not stream-ordered (gloo, the rehearsal transport)
+        gets host tensors: what it does with device pointers is its own business, and receives that
+        land in device memory behind the GPU's caches were seen to leave a later kernel with stale
+        values now and then."""
+        if not items:
+            return
+        staged = self.cuda and not self.stream_ordered
+        if self.cuda and not self.stream_ordered:
+            (self.comm_stream if self.overlap else self.compute_stream).synchronize()
+        bufs = []
+        for kind, t, _, _ in items:
+            if not staged:
+                bufs.append(t)
+            elif kind == "send":
+                bufs.append(t.cpu())
+            else:
+                bufs.append(torch.empty(t.shape, dtype=t.dtype, device="cpu"))
+        ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, b, self._peer(peer), self.group, tag=tag)
+               for (kind, _, peer, tag), b in zip(items, bufs)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if staged:
+            for (kind, t, _, _), b in zip(items, bufs):
+                if kind == "recv":
+                    t.copy_(b)
 
     def _sweep_fused(self, y_lo: int, y_hi: int, k: int) -> None:
         if y_lo >= y_hi:
@@ -437,8 +457,10 @@ class SlabSimulation:
         self._join_halo()
         self.backend.max_velocity_dev(self._max, self.f, self.G, self.G + self.n)
         if self.world > 1:
-            if not self.stream_ordered:
-                torch.cuda.synchronize(self.device)
+            if self.cuda and not self.stream_ordered:
+                m = self._max[:1].cpu()             # see _transfer
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+                return float(m.item())
             dist.all_reduce(self._max[:1], op=dist.ReduceOp.MAX, group=self.group)
         return float(self._max[0].item())
 
@@ -452,17 +474,16 @@ class SlabSimulation:
         mine = self.interior().contiguous()
         if self.world == 1:
             return mine
-        if not self.stream_ordered:
-            torch.cuda.synchronize(self.device)
+        staged = self.cuda and not self.stream_ordered      # see _transfer
         if self.rank == 0:
             parts = [mine]
             for r in range(1, self.world):
                 nr, _ = slab_rows(self.ny_glob, self.world, r)
-                part = torch.empty((9, nr, self.nx), dtype=mine.dtype, device=self.device)
+                part = torch.empty((9, nr, self.nx), dtype=mine.dtype, device="cpu" if staged else self.device)
                 dist.recv(part, self._peer(r), group=self.group)
-                parts.append(part)
+                parts.append(part.to(self.device))
             return torch.cat(parts, dim=1)
-        dist.send(mine, self._peer(0), group=self.group)
+        dist.send(mine.cpu() if staged else mine, self._peer(0), group=self.group)
         return None
 
     def synchronize(self) -> None:

@@ -85,3 +85,26 @@ class OracleBackend:
 
     def compute_velocities(self, vel, f, y_lo, y_hi):
         vel.numpy()[:] = orc.compute_velocities(f.numpy(), y_lo, y_hi)
+
+
+class OracleCartBackend:
+    """CPU stand-in for the block kernels of lbm_amd.cart (halo ring of one node, inner / outer
+    sweeps), built on the oracle."""
+
+    def init_shearwave(self, f, rho, u, y_below, y_glob):
+        a = f.numpy()
+        interior = np.ascontiguousarray(a[:, 1:a.shape[1] - 1])
+        t = a.dtype.type
+        orc.init_shearwave(interior, t(rho), t(u), y_below, y_glob)
+        a[:, 1:a.shape[1] - 1] = interior
+
+    def pull_inner(self, f, buf, om, LX, LY, HX, HY):
+        a = f.numpy()
+        orc.pull_periodic_inner(a, buf.numpy(), a.dtype.type(om), LX, LY, HX, HY)
+
+    def pull_outer(self, f, buf, om):
+        a = f.numpy()
+        orc.pull_periodic_outer(a, buf.numpy(), a.dtype.type(om))
+
+    def compute_velocities(self, vel, f, y_lo, y_hi):
+        vel.numpy()[...] = orc.compute_velocities(f.numpy(), y_lo, y_hi)

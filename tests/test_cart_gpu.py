@@ -1,0 +1,72 @@
+"""The 2-D Cartesian decomposition (lbm_amd.cart) on the GPU: the HIP inner / outer sweeps on a
+block with a halo ring, the packing and the second stream -- first with the rank as its own
+neighbour in both directions, then four and six ranks sharing cuda:0 over gloo (RCCL refuses
+several ranks on one GPU)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+from test_parity_gpu import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("overlap", [True, False])
+def test_one_rank_equals_the_oracle(dtype, overlap):
+    from lbm_amd.cart import CartSimulation
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    for nx, ny, steps, omega in ((64, 48, 40, 0.8), (131, 37, 25, 1.4), (2, 2, 9, 1.0), (1024, 300, 12, 0.5)):
+        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap)
+        sim.step(steps)
+        want, _ = orc.run("shear", "pull", nx, ny, steps, omega, npdt)
+        assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 {nx}x{ny}")
+        assert sim.max_velocity() == float(orc.max_velocity(want))
+        assert sim.t == steps
+
+
+CASES = [("float32", 256, 96, 30, 0.8), ("float64", 67, 45, 40, 1.3), ("float32", 1030, 517, 12, 0.5)]
+
+
+def _worker(rank, world, store_path, out_path):
+    sys.path.insert(0, ROOT)
+    from lbm_amd.cart import CartSimulation
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
+    results = {}
+    try:
+        for case in CASES:
+            tdt, nx, ny, steps, omega = case
+            sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0")
+            sim.step(steps)
+            vmax = sim.max_velocity()
+            full = sim.gather_populations()
+            if rank == 0:
+                results[case] = (full.cpu().numpy(), vmax, sim.dims)
+        if rank == 0:
+            torch.save(results, out_path)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 6])
+def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "out.pt")
+        mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), out), nprocs=world, join=True)
+        results = torch.load(out, weights_only=False)
+    for (tdt, nx, ny, steps, omega), (full, vmax, dims) in results.items():
+        assert dims == ((2, 2) if world == 4 else (3, 2))
+        want, _ = orc.run("shear", "pull", nx, ny, steps, omega, getattr(np, tdt))
+        assert_bits_equal(full, want, f"cart {dims} {tdt} {nx}x{ny}")
+        assert vmax == float(orc.max_velocity(want))
