@@ -262,6 +262,17 @@ int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
 {
     if (LX >= HX || LY >= HY) return LBM_OK;
     const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
+    constexpr int V = vec_width<T>();
+    if (PULL && HX - LX >= 4 * (uint64_t)V) {
+        const uint64_t lanes = (HX - LX + V - 1) / V;
+        const unsigned block = pick_block(lanes);
+        const dim3 grid = sweep_grid(lanes, block, HY - LY);
+        const size_t lds = residency_ballast(block, sizeof(T), true, nx, ny);
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_pull_inner_vec<T, V, B>), grid, dim3(B), lds, stream, (const T *)f_,
+                               (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, (T)om_))
+        return launch_status("pull periodic inner");
+    }
     const unsigned block = pick_block(HX - LX);
     const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
     constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;

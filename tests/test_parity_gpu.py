@@ -126,7 +126,20 @@ def test_halo_forms_match_oracle(dtype):
         getattr(ops, f"{kind}_periodic_inner")(d_f, d_b, float(om), 2, 2, nx - 2, ny - 2)
         getattr(ops, f"{kind}_periodic_outer")(d_f, d_b, float(om), nx, ny)
         assert_bits_equal(d_b.cpu().numpy(), want, f"{kind} inner+outer")
-    nx = 256
+    # rectangles of every width around the change from the element-wise to the vector kernel, odd
+    # bounds, single rows; nothing outside the rectangle may be written
+    for nx, ny, LX, LY, HX, HY in ((70, 23, 1, 1, 69, 22), (70, 23, 3, 5, 64, 6), (40, 9, 2, 2, 17, 7),
+                                   (40, 9, 2, 2, 18, 7), (40, 9, 5, 1, 24, 8), (1031, 12, 1, 1, 1030, 11),
+                                   (1031, 12, 7, 3, 1000, 9), (12, 40, 1, 1, 11, 39)):
+        f = (1.0 / 9 + 0.02 * rng.standard_normal((9, ny, nx))).astype(dtype)
+        d_f = torch.from_numpy(f).cuda()
+        for kind in ("pull", "push"):
+            want = np.full_like(f, -7.0)
+            getattr(orc, f"{kind}_periodic_inner")(f, want, om, LX, LY, HX, HY)
+            d_b = torch.full_like(d_f, -7.0)
+            getattr(ops, f"{kind}_periodic_inner")(d_f, d_b, float(om), LX, LY, HX, HY)
+            assert_bits_equal(d_b.cpu().numpy(), want, f"{kind} inner {nx}x{ny} [{LX},{HX})x[{LY},{HY})")
+    nx, ny = 256, 23
     f = (1.0 / 9 + 0.02 * rng.standard_normal((9, ny, nx))).astype(dtype)
     d_f = torch.from_numpy(f).cuda()
     for kind in ("pull", "push"):
