@@ -56,6 +56,8 @@ def parse():
                     help="strong scaling: fixed global height split over the ranks (overrides --ny-per-gpu), "
                          "e.g. --nx 32768 --ny-global 32768")
     ap.add_argument("--omega", type=float, default=0.5)
+    ap.add_argument("--rolled", action="store_true",
+                    help="the reference's UNROLL_LOOPS=false arithmetic in the periodic sweeps (shear scene)")
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa",
                     help="aos = [NY][NX][9] arrays, the reference's COALESCING=false (single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,6 +167,8 @@ def main():
         ny_glob = args.ny_global
         ny_loc = -(-ny_glob // world)   # the largest slab (remainder rows go to the lowest ranks)
 
+    if args.rolled:
+        ops.set_unroll_loops(False)
     if args.layout == "aos":
         if world != 1 or args.slab:
             raise SystemExit("--layout aos runs on one GPU without the slab path")
@@ -224,7 +228,7 @@ def main():
         achieved = alg_bytes / launch_s / 1e9
         workload = (f"{'shear-wave decay' if args.scene == 'shear' else 'lid-driven cavity'} "
                     f"{nx}x{ny_glob} {args.precision} {args.scheme}")
-        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "")
+        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "") + ("-rolled" if args.rolled else "")
         # profiles are keyed by the step count of the dominant launches (a run whose length is not a
         # multiple of it ends with one shorter launch)
         k_dom = min(args.steps, -(-args.steps // n_launch))
@@ -246,7 +250,8 @@ def main():
             "data": "synthetic" if not rehearse else "synthetic (REHEARSAL over gloo on shared GPUs: not a measurement)",
             "config": {
                 "workload": workload,
-                "scene": args.scene, "scheme": args.scheme, "layout": args.layout, "nx": nx, "ny_global": ny_glob,
+                "scene": args.scene, "scheme": args.scheme, "layout": args.layout,
+                "arithmetic": "rolled loops (UNROLL_LOOPS=false)" if args.rolled else "unrolled", "nx": nx, "ny_global": ny_glob,
                 "ny_per_gpu": ny_loc, "omega": args.omega,
                 "decomposition": ("single device" if world == 1 and not args.slab else
                                   f"{world} y-slab(s), {sim.G} ghost row(s) per edge refreshed every "

@@ -61,6 +61,17 @@ enum { LBM_LAYOUT_SOA = 0, LBM_LAYOUT_AOS = 1 };
 int lbm_set_layout(int layout);
 int lbm_get_layout(void);
 
+/* The reference's UNROLL_LOOPS switch (macros.h:6) as a process-wide run-time setting.  It selects
+ * between two spellings of the BGK relaxation in the periodic sweeps: pull_periodic / push_periodic
+ * (pull-push.cpp:5-73, :124-186; unrolled != 0, the default) and pull_periodic_for /
+ * push_periodic_for (pull-push.cpp:77-120, :190-243; unrolled == 0), which round the equilibrium
+ * differently (4.5*(c*c) instead of (4.5*c)*c) and so differ in the last bits.  Each is followed
+ * literally.  The lid-driven sweeps have one spelling in the reference and ignore the switch.  With
+ * unrolled == 0 the one-step periodic entry points run element-wise kernels, the *_fused ones the
+ * multi-step kernels (fp32: rows of an even length >= 4); [NY][NX][9] arrays are not supported. */
+int lbm_set_unroll_loops(int unrolled);
+int lbm_get_unroll_loops(void);
+
 /* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
  * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (64, 128, 256 or 512) and the
  * cap on resident waves per compute unit for the sweep kernels (1..32; the sweeps stream fastest

@@ -23,6 +23,8 @@ SIGNATURES = {
     "lbm_abi_version": (_int, []),
     "lbm_set_layout": (_int, [_int]),
     "lbm_get_layout": (_int, []),
+    "lbm_set_unroll_loops": (_int, [_int]),
+    "lbm_get_unroll_loops": (_int, []),
     "lbm_set_launch_shape": (_int, [_uint, _uint]),
     "lbm_init_shearwave": (_int, [_ptr, _int, _u64, _u64, _dbl, _dbl, _u64, _u64, _uint, _ptr]),
     "lbm_init_rest": (_int, [_ptr, _int, _u64, _u64, _dbl, _ptr]),

@@ -45,6 +45,10 @@ int fail(int status, const char *fmt, ...)
 // memory layout of every distribution array passed in (lbm_set_layout)
 int g_layout = LBM_LAYOUT_SOA;
 
+// 0: the unrolled spelling of the relaxation (default), 1: the reference's UNROLL_LOOPS=false
+// spelling (periodic sweeps only; lbm_set_unroll_loops)
+int g_rolled = 0;
+
 // launch-shape hint (lbm_set_launch_shape)
 unsigned g_threads_x = 0;
 unsigned g_waves_per_cu = 0;
@@ -214,6 +218,16 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
     constexpr int V = vec_width<T>();
     const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, wrap_y);
     const uint64_t rows = y_hi - y_lo;
+    if (g_rolled) {
+        // the rolled arithmetic lives in the element-wise kernel and in the multi-step kernels
+        const unsigned block = pick_block(nx);
+        const dim3 grid = sweep_grid(nx, block, rows);
+        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, true>), grid, dim3(B), 0, stream, f, buf, g,
+                               0u, (uint32_t)nx, 1, om, (T)0))
+        return launch_status(PULL ? "pull periodic (rolled)" : "push periodic (rolled)");
+    }
     if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
@@ -263,6 +277,15 @@ int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     if (LX >= HX || LY >= HY) return LBM_OK;
     const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
     constexpr int V = vec_width<T>();
+    if (g_rolled) {
+        const unsigned block = pick_block(HX - LX);
+        const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
+        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, true>), grid, dim3(B), 0, stream, (const T *)f_,
+                               (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
+        return launch_status("periodic inner (rolled)");
+    }
     if (PULL && HX - LX >= 4 * (uint64_t)V) {
         const uint64_t lanes = (HX - LX + V - 1) / V;
         const unsigned block = pick_block(lanes);
@@ -304,8 +327,12 @@ int sweep_outer(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
 {
     const uint64_t lanes = (nx - 2) + (ny - 4);
     constexpr int B = 256;
-    hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
-                       stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
+    if (g_rolled)
+        hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, true>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
+                           stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
+    else
+        hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
+                           stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
     return launch_status("periodic outer");
 }
 
@@ -423,7 +450,7 @@ bool fused_supported(uint64_t nx)
     return nx >= 2;
 }
 
-template <typename T, int V, bool PUSH, bool LID, bool AOS>
+template <typename T, int V, bool PUSH, bool LID, bool AOS, bool ROLLED = false>
 int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
@@ -462,7 +489,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const dim3 grid((unsigned)(nstrips * nsegs_grid)), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
-        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS>), grid, block, 0, stream, f, buf, g, om, df); \
+        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ROLLED>), grid, block, 0, stream, f, buf, g, om, df); \
         break;
     switch (k) {
         LBM_FUSED_CASE(1)
@@ -490,6 +517,17 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
     const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8);
+    if constexpr (!LID) {
+        if (g_rolled) {
+            if (g_layout == LBM_LAYOUT_AOS)
+                return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
+            if (narrow)
+                return fail(LBM_ERR_UNSUPPORTED,
+                            "the rolled arithmetic takes several steps per call only for fp32 rows of an even length >= 4 (nx=%llu)",
+                            (unsigned long long)nx);
+            return launch_fused<T, V8, PUSH, false, false, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+        }
+    }
     if (g_layout == LBM_LAYOUT_AOS) {
         if constexpr (V8 > 1) {
             if (narrow)
@@ -511,7 +549,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
     if (k < 1 || k > max_fused_steps(prec))
         return fail(LBM_ERR_INVALID_ARGUMENT, "step count %d outside 1..%d", k, max_fused_steps(prec));
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
-    const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
+    const bool supported = lbm_fused_max_steps(prec, nx) > 1;
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
     // length the fused kernels cannot take
     if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
@@ -521,8 +559,9 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
         return fail(LBM_ERR_INVALID_ARGUMENT,
                     "%d fused steps of rows [%llu,%llu) need %d ghost rows on either side inside [0,%llu)",
                     k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
-    if (!(prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx)))
-        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes (nx=%llu)",
+    if (!supported)
+        return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes%s (nx=%llu)",
+                    g_rolled ? ", and an even number of fp32 nodes with the rolled arithmetic" : "",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -582,6 +621,8 @@ int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, d
     if (nx < 2)
         return fail(LBM_ERR_UNSUPPORTED, "[NY][NX][9] arrays need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
+    if (!LID && g_rolled)
+        return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
     const bool whole = y_lo == 0 && y_hi == ny && (LID ? (y_goff == 0 && ny_glob == ny) : wrap_y != 0);
     if (!PULL && !whole)
         return fail(LBM_ERR_UNSUPPORTED,
@@ -777,6 +818,14 @@ int lbm_set_layout(int layout)
 
 int lbm_get_layout(void) { return g_layout; }
 
+int lbm_set_unroll_loops(int unrolled)
+{
+    g_rolled = unrolled ? 0 : 1;
+    return LBM_OK;
+}
+
+int lbm_get_unroll_loops(void) { return g_rolled ? 0 : 1; }
+
 int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu)
 {
     if (threads_x != 0 && threads_x != 64 && threads_x != 128 && threads_x != 256 && threads_x != 512)
@@ -870,7 +919,9 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
 int lbm_fused_max_steps(int prec, uint64_t nx)
 {
     if (prec != LBM_F32 && prec != LBM_F64) return 0;
-    const bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
+    bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
+    // the rolled arithmetic is built for 8-byte lanes only, and not for [NY][NX][9] arrays
+    if (g_rolled && (g_layout == LBM_LAYOUT_AOS || (prec == LBM_F32 && (nx % 2 != 0 || nx < 4)))) ok = false;
     return ok ? max_fused_steps(prec) : 1;
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)

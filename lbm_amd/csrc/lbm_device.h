@@ -161,17 +161,59 @@ __device__ __forceinline__ void collide_x(const X f_0, const X f_1, const X f_2,
     o[5] = f_5 + om * ((w_1_36 * (one + three * uxpuy + uxpuy_2 - usq)) - f_5);
 }
 
-template <typename T>
+// The reference's other spelling of the same relaxation, compiled there when UNROLL_LOOPS is false
+// (pull_periodic_for / push_periodic_for, pull-push.cpp:90-119, :204-231): loops over the nine
+// directions with the lattice vectors and weights in tables.  Density and velocity come out the same
+// (adding 0 and multiplying by 0 or +-1 change nothing that is finite); the equilibrium is
+// (w*rho) * (((1 + 3c) + 4.5*(c*c)) - 1.5*u2) with c = cx*ux + cy*uy, where the unrolled form has
+// (4.5*c)*c -- a different rounding, so the two spellings differ in the last bits and each is
+// followed literally.
+template <typename X, typename T>
+__device__ __forceinline__ void collide_for_x(const X f_0, const X f_1, const X f_2, const X f_3,
+                                              const X f_4, const X f_5, const X f_6, const X f_7,
+                                              const X f_8, const T om_, X (&o)[9])
+{
+    const X om = X(om_);
+    const X f[9] = {f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8};
+    X rho = X(T(0.));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rho = rho + f[i];
+    const X rho_inv = X(T(1.0)) / rho;
+    const T cx[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
+    const T cy[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+    X ux = X(T(0.)), uy = X(T(0.));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        ux = ux + f[i] * X(cx[i]);
+        uy = uy + f[i] * X(cy[i]);
+    }
+    ux = ux * rho_inv;
+    uy = uy * rho_inv;
+    const T w[9] = {T(4. / 9.), T(1. / 9.), T(1. / 9.), T(1. / 9.), T(1. / 9.),
+                    T(1. / 36.), T(1. / 36.), T(1. / 36.), T(1. / 36.)};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const X cx_ux = X(cx[i]) * ux;
+        const X cy_uy = X(cy[i]) * uy;
+        const X c_i_u_r = cx_ux + cy_uy;
+        const X u_2 = ux * ux + uy * uy;
+        const X f_eq = X(w[i]) * rho * (X(T(1)) + X(T(3)) * c_i_u_r + X(T(4.5)) * (c_i_u_r * c_i_u_r) - X(T(1.5)) * u_2);
+        o[i] = f[i] + om * (f_eq - f[i]);
+    }
+}
+
+template <typename T, bool ROLLED = false>
 __device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, const T f_3,
                                         const T f_4, const T f_5, const T f_6, const T f_7,
                                         const T f_8, const T om, T (&o)[9])
 {
-    collide_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    if constexpr (ROLLED) collide_for_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    else                  collide_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
 }
 
 // Relax the V nodes of one lane: c[q][i] -> o[q][i].  fp32 nodes go through the arithmetic in
 // pairs (packed instructions), everything else one by one.
-template <typename T, int V, bool PAIRS = true>
+template <typename T, int V, bool PAIRS = true, bool ROLLED = false>
 __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], const T om)
 {
     if constexpr (PAIRS && sizeof(T) == 4 && V % 2 == 0) {
@@ -181,7 +223,8 @@ __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], 
             pair_t in[9], r[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) { in[q].x = c[q][i]; in[q].y = c[q][i + 1]; }
-            collide_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
+            if constexpr (ROLLED) collide_for_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
+            else                  collide_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
 #pragma unroll
             for (int q = 0; q < 9; ++q) { o[q][i] = r[q].x; o[q][i + 1] = r[q].y; }
         }
@@ -189,7 +232,7 @@ __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], 
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             T r[9];
-            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
+            collide<T, ROLLED>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
 #pragma unroll
             for (int q = 0; q < 9; ++q) o[q][i] = r[q];
         }
@@ -422,7 +465,7 @@ k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 // ------------------------------------------------------------------------------------------
 // Single-node forms (any nx, explicit neighbour indices).  Used by the scalar kernels, by the
 // halo'd inner/outer forms and by the wall lanes of the lid kernels.
-template <typename T>
+template <typename T, bool ROLLED = false>
 __device__ __forceinline__ void pull_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
                                           uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
                                           uint32_t xr, uint32_t yd, uint32_t yu, T om)
@@ -437,12 +480,12 @@ __device__ __forceinline__ void pull_node(const T *__restrict__ f, T *__restrict
     const T f_2 = rowp(f, plane, 2, yd, nx)[x];
     const T f_5 = rowp(f, plane, 5, yd, nx)[xl];
     T o[9];
-    collide<T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    collide<T, ROLLED>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
 #pragma unroll
     for (int q = 0; q < 9; ++q) rowp(buf, plane, q, y, nx)[x] = o[q];
 }
 
-template <typename T>
+template <typename T, bool ROLLED = false>
 __device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
                                           uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
                                           uint32_t xr, uint32_t yd, uint32_t yu, T om)
@@ -451,7 +494,7 @@ __device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict
 #pragma unroll
     for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
     T o[9];
-    collide<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
+    collide<T, ROLLED>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
     rowp(buf, plane, 7, yd, nx)[xl] = o[7];
     rowp(buf, plane, 4, yd, nx)[x] = o[4];
     rowp(buf, plane, 8, yd, nx)[xr] = o[8];
@@ -792,7 +835,8 @@ k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, cons
 // ------------------------------------------------------------------------------------------
 // Scalar kernels: one node per lane over the rectangle [x_lo,x_hi) x [y_lo,y_hi).  Any nx.
 
-template <typename T, int MODE, int BLOCK>
+// ROLLED (periodic modes only): the reference's UNROLL_LOOPS=false arithmetic (collide_for_x).
+template <typename T, int MODE, int BLOCK, bool ROLLED = false>
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint32_t x_lo,
                uint32_t x_hi, int wrap_x, const T om, const T df_lid)
@@ -808,8 +852,8 @@ k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint3
             const uint32_t xr = wrap_x ? ((x + 1 == g.nx) ? 0u : x + 1) : x + 1;
             const uint32_t xl = wrap_x ? ((x == 0) ? g.nx - 1 : x - 1) : x - 1;
             const uint32_t yu = row_up(g, y), yd = row_down(g, y);
-            if (MODE == kPullPeriodic) pull_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
-            else                       push_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            if (MODE == kPullPeriodic) pull_node<T, ROLLED>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            else                       push_node<T, ROLLED>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
         } else {
             const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
             const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
@@ -823,7 +867,7 @@ k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint3
 // Ring of a halo'd array: pull_periodic_outer / push_periodic_outer (pull-push.cpp:335-429).
 // Lane i < nx-2 handles x=i+1 at y=1 and y=ny-2; lane nx-2+j, j < ny-4, handles y=j+2 at x=1 and
 // x=nx-2.
-template <typename T, bool PULL, int BLOCK>
+template <typename T, bool PULL, int BLOCK, bool ROLLED = false>
 __global__ void __launch_bounds__(BLOCK)
 k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t ny, const T om)
 {
@@ -839,18 +883,18 @@ k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t
         return;
     }
     if (PULL) {
-        pull_node<T>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        pull_node<T, ROLLED>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
         if (xb != xa || yb != ya)
-            pull_node<T>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+            pull_node<T, ROLLED>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
     } else {
-        push_node<T>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        push_node<T, ROLLED>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
         if (xb != xa || yb != ya)
-            push_node<T>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+            push_node<T, ROLLED>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// pull_periodic_inner (pull-push.cpp:448-459 over the rectangle [LX,HX) x [g.y_lo,g.y_hi) of an array
+// pull_periodic_inner (pull-push.cpp:291-310 over the rectangle [LX,HX) x [g.y_lo,g.y_hi) of an array
 // with a halo): no node of the rectangle touches the array edge, so nothing wraps.  A lane takes V
 // nodes from LX + lane * V with element-aligned 128-bit accesses; the lane that would cross HX goes
 // node by node.  2.2 x the element-wise kernel at 16384^2 fp32.

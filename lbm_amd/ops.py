@@ -51,6 +51,28 @@ def layout(name: str):
         set_layout(before)
 
 
+def set_unroll_loops(unrolled: bool) -> None:
+    """The reference's UNROLL_LOOPS switch (macros.h:6): False selects the arithmetic of
+    pull_periodic_for / push_periodic_for (pull-push.cpp:77-120, :190-243) in the periodic sweeps,
+    which differs from the default in the last bits.  Process-wide."""
+    capi.call("lbm_set_unroll_loops", 1 if unrolled else 0)
+
+
+def get_unroll_loops() -> bool:
+    return bool(capi.load().lbm_get_unroll_loops())
+
+
+@contextlib.contextmanager
+def unroll_loops(unrolled: bool):
+    """`with ops.unroll_loops(False): ...` -- switch the process-wide arithmetic for a block."""
+    before = get_unroll_loops()
+    set_unroll_loops(unrolled)
+    try:
+        yield
+    finally:
+        set_unroll_loops(before)
+
+
 def population_shape(nx: int, ny: int):
     """Shape of a population tensor of an nx x ny lattice in the current layout."""
     return (ny, nx, Q) if _layout == AOS else (Q, ny, nx)

@@ -20,6 +20,11 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* 0: pull_periodic / push_periodic (UNROLL_LOOPS true, the default); 1: the *_for spelling. */
+static int orc_rolled = 0;
+void orc_set_rolled(int rolled) { orc_rolled = rolled; }
+int orc_get_rolled(void) { return orc_rolled; }
+
 #define FLT float
 #define SUFFIX _f32
 #include "lbm_oracle_impl.h"

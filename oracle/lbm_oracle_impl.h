@@ -58,6 +58,42 @@ static inline void FN(collide)(const FLT in[9], FLT out[9], const FLT OMEGA)
     out[5] = f_5 + OMEGA * ((w_1_36 * (1 + 3 * uxpuy + uxpuy_2 - usq)) - f_5); /* :72 */
 }
 
+/* The reference's other spelling of the relaxation, compiled when UNROLL_LOOPS is false:
+ * pull_periodic_for (pull-push.cpp:90-119) and push_periodic_for (:204-231) hold the same loops. */
+static inline void FN(collide_for)(const FLT f[9], FLT out[9], const FLT OMEGA)
+{
+    FLT rho = 0.;                                                          /* :91-94 */
+    for (unsigned i = 0; i < 9; ++i) rho += f[i];
+    const FLT f1 = (FLT)1.0;
+    const FLT rho_inv = f1 / rho;                                          /* :96 */
+    const FLT cx[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};                      /* :99-100 */
+    const FLT cy[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+    FLT ux = 0., uy = 0.;
+    for (unsigned i = 0; i < 9; ++i) {                                     /* :103-106 */
+        ux += f[i] * cx[i];
+        uy += f[i] * cy[i];
+    }
+    ux *= rho_inv;
+    uy *= rho_inv;
+    const FLT w[9] = {4. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 36., 1. / 36., 1. / 36., 1. / 36.};
+    for (unsigned i = 0; i < 9; ++i) {                                     /* :112-119 */
+        const FLT cx_ux = cx[i] * ux;
+        const FLT cy_uy = cy[i] * uy;
+        const FLT c_i_u_r = cx_ux + cy_uy;
+        const FLT u_2 = ux * ux + uy * uy;
+        const FLT f_eq = w[i] * rho * (((FLT)1) + ((FLT)3) * c_i_u_r + ((FLT)4.5) * (c_i_u_r * c_i_u_r) - ((FLT)1.5) * u_2);
+        out[i] = f[i] + OMEGA * (f_eq - f[i]);
+    }
+}
+
+/* What the periodic sweeps call: pull-push.cpp:259-263, :281-285 and the six further
+ * `#if UNROLL_LOOPS` sites of the inner / outer forms.  The lid-driven sweep has one spelling. */
+static inline void FN(collide_sel)(const FLT in[9], FLT out[9], const FLT OMEGA)
+{
+    if (orc_rolled) FN(collide_for)(in, out, OMEGA);
+    else FN(collide)(in, out, OMEGA);
+}
+
 /* Equilibrium used by the initialisers: init.cpp:57-84.  The bracket is evaluated in double even
  * when FLT is float, because 9./2. and 3./2. are double literals (init.cpp:78-83); 1+3*cu and
  * cu*cu and u_2 are formed in FLT first. */
@@ -123,7 +159,7 @@ static inline void FN(pull_node)(const FLT *f, FLT *buf, uint64_t nx, uint64_t n
     in[6] = AT(f, 6, yd, xr);
     in[2] = AT(f, 2, yd, x);
     in[5] = AT(f, 5, yd, xl);
-    FN(collide)(in, out, OMEGA);
+    FN(collide_sel)(in, out, OMEGA);
     for (unsigned q = 0; q < 9; ++q) AT(buf, q, y, x) = out[q];
 }
 
@@ -134,7 +170,7 @@ static inline void FN(push_node)(const FLT *f, FLT *buf, uint64_t nx, uint64_t n
 {
     FLT in[9], out[9];
     for (unsigned q = 0; q < 9; ++q) in[q] = AT(f, q, y, x);
-    FN(collide)(in, out, OMEGA);
+    FN(collide_sel)(in, out, OMEGA);
     AT(buf, 7, yd, xl) = out[7];
     AT(buf, 4, yd, x) = out[4];
     AT(buf, 8, yd, xr) = out[8];
@@ -166,7 +202,7 @@ static inline void FN(pull_row_interior)(const FLT *restrict r0, const FLT *rest
         in[7] = r7[x + 1]; in[4] = r4[x]; in[8] = r8[x - 1];
         in[3] = r3[x + 1]; in[0] = r0[x]; in[1] = r1[x - 1];
         in[6] = r6[x + 1]; in[2] = r2[x]; in[5] = r5[x - 1];
-        FN(collide)(in, out, OMEGA);
+        FN(collide_sel)(in, out, OMEGA);
         w0[x] = out[0]; w1[x] = out[1]; w2[x] = out[2]; w3[x] = out[3]; w4[x] = out[4];
         w5[x] = out[5]; w6[x] = out[6]; w7[x] = out[7]; w8[x] = out[8];
     }
@@ -223,7 +259,7 @@ void FN(orc_push_rows)(const FLT *f, FLT *buf, uint64_t nx, uint64_t ny, uint64_
                 FLT in[9], out[9];
                 in[0] = r0[x]; in[1] = r1[x]; in[2] = r2[x]; in[3] = r3[x]; in[4] = r4[x];
                 in[5] = r5[x]; in[6] = r6[x]; in[7] = r7[x]; in[8] = r8[x];
-                FN(collide)(in, out, OMEGA);
+                FN(collide_sel)(in, out, OMEGA);
                 w7[x - 1] = out[7]; w4[x] = out[4]; w8[x + 1] = out[8];
                 w3[x - 1] = out[3]; w0[x] = out[0]; w1[x + 1] = out[1];
                 w6[x - 1] = out[6]; w2[x] = out[2]; w5[x + 1] = out[5];

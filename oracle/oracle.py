@@ -86,6 +86,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def set_rolled(rolled: bool) -> None:
+    """Periodic sweeps follow pull_periodic_for / push_periodic_for (the reference's
+    UNROLL_LOOPS=false build, pull-push.cpp:77-120, :190-243) instead of the unrolled spelling."""
+    lib().orc_set_rolled(1 if rolled else 0)
+
+
+def get_rolled() -> bool:
+    return bool(lib().orc_get_rolled())
+
+
 def num_threads() -> int:
     """OpenMP threads the oracle's row loops use."""
     fn = lib().orc_num_threads

@@ -349,6 +349,10 @@ int main(int argc, char *argv[])
     // macros.h:7 / global.h:37-41: f and buf are [NY][NX][9] for the whole run
     die_lbm(lbm_set_layout(LBM_LAYOUT_AOS), "set_layout");
 #endif
+#if !UNROLL_LOOPS
+    // macros.h:6 / pull-push.cpp:259-263: the periodic sweeps use the *_for spelling of the relaxation
+    die_lbm(lbm_set_unroll_loops(0), "set_unroll_loops");
+#endif
     try {
         r.o = parse_args(argc, argv);
         if (r.o.use_file) {

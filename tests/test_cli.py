@@ -129,3 +129,27 @@ def test_coalescing_false_build_prints_the_same(tmp_path):
         assert a.stdout == b.stdout and a.stdout != "", args
     p = run_main("-nx", 256, "-ny", 128, "-of", 0, "-s", 100, exe="main_aos")
     check_stderr_contract(p.stderr, 256, 128, 100)
+
+
+@pytest.mark.gpu
+def test_unroll_loops_false_build_follows_the_rolled_spelling():
+    """build/main_rolled is the driver compiled with UNROLL_LOOPS=false (reference macros.h:6): the
+    periodic sweeps use pull_periodic_for / push_periodic_for, the cavity is unchanged."""
+    orc.set_rolled(True)
+    try:
+        for scheme, flag in (("pull", ()), ("push", ("-push",))):
+            p = run_main("-nx", 96, "-ny", 40, "-w", 1.0, "-s", 301, "-of", 100, "-omv", *flag, exe="main_rolled")
+            _, s = orc.run("shear", scheme, 96, 40, 301, 1.0, np.float32, out_every=100)
+            assert p.stdout == "".join(orc.fmt(v) + "," for v in s)
+        p = run_main("-nx", 64, "-ny", 48, "-w", 0.7, "-s", 120, "-of", 119, "-ov", exe="main_rolled")
+        fr, _ = orc.run("shear", "pull", 64, 48, 119, 0.7, np.float32)
+        start = orc.alloc(64, 48, np.float32)
+        orc.init_shearwave(start, np.float32(1), np.float32(0.1))
+        want = ""
+        for state in (start, fr):
+            want += "\n".join(",".join(orc.fmt(v) for v in r) for r in orc.velocity_magnitudes(state)) + "\n#\n"
+        assert p.stdout == want
+    finally:
+        orc.set_rolled(False)
+    args = ("-nx", 24, "-ny", 16, "-w", 1.7, "-s", 41, "-of", 20, "-ovf", "-ld")
+    assert run_main(*args).stdout == run_main(*args, exe="main_rolled").stdout

@@ -200,3 +200,25 @@ def test_max_velocity_ignores_nan_and_starts_at_minus_1e30():
     assert orc.max_velocity(f) == m0
     f[:] = np.nan
     assert orc.max_velocity(f) == np.float32(-1e30)
+
+
+def test_rolled_spelling_differs_in_the_last_bits_only():
+    """pull_periodic_for / push_periodic_for (pull-push.cpp:77-120, :190-243; UNROLL_LOOPS=false):
+    same physics, other rounding of the equilibrium.  The cavity sweep has one spelling."""
+    for dtype, tol in ((np.float32, 2e-6), (np.float64, 1e-14)):
+        for scheme in ("pull", "push"):
+            a, sa = orc.run("shear", scheme, 48, 36, 200, 0.8, dtype, out_every=100)
+            orc.set_rolled(True)
+            try:
+                assert orc.get_rolled()
+                b, s = orc.run("shear", scheme, 48, 36, 200, 0.8, dtype, out_every=100)
+                lid_rolled, _ = orc.run("lid", "push", 24, 16, 50, 1.2, dtype)
+            finally:
+                orc.set_rolled(False)
+            assert (a != b).any() and np.abs(a.astype(np.float64) - b.astype(np.float64)).max() < tol
+            assert s[0] == pytest.approx(0.1, rel=1e-6)
+            nu = (1 / 0.8 - 0.5) / 3
+            assert float(s[1]) == pytest.approx(0.1 * np.exp(-nu * (2 * np.pi / 36) ** 2 * 100), rel=1e-2)
+            assert float(s[1]) == pytest.approx(float(sa[1]), rel=1e-5)   # the same decay as the default spelling
+            lid, _ = orc.run("lid", "push", 24, 16, 50, 1.2, dtype)
+            assert (lid == lid_rolled).all()
