@@ -86,11 +86,13 @@ def test_viscosity_table_is_the_analytic_curve(decays):
 @pytest.mark.parametrize("prec,dtype", [("fp32", np.float32), ("fp64", np.float64)])
 def test_oracle_reproduces_the_start_of_the_config1_series(golden_dir, prec, dtype):
     """First five values of `-nx 1024 -ny 1024 -w 0.5 -s 50000 -of 500 -omv` as the reference's own
-    sources print them (tests/golden/config1_series.json); the whole series is checked on the GPU."""
+    sources print them (tests/golden/config1_series.json); the whole series is checked on the GPU.
+    The shear wave does not vary along x and every column goes through the same arithmetic, so a
+    lattice of 16 columns prints what 1024 columns print (the GPU test runs the full width)."""
     with open(os.path.join(golden_dir, "config1_series.json")) as fh:
         gold = json.load(fh)
     want_text = gold[f"{prec}_text"].split(",")[:5]
-    _, samples = orc.run("shear", "pull", 1024, 1024, 2001, 0.5, dtype, out_every=500)
+    _, samples = orc.run("shear", "pull", 16, 1024, 2001, 0.5, dtype, out_every=500)
     got_text = [orc.fmt(v) for v in samples]
     got = np.array([float(v) for v in got_text])
     want = np.array([float(v) for v in want_text])
@@ -99,7 +101,7 @@ def test_oracle_reproduces_the_start_of_the_config1_series(golden_dir, prec, dty
     else:
         np.testing.assert_allclose(got, want, rtol=DECAY_RTOL_STRICT)
         with orc.variant("fma"):
-            _, samples = orc.run("shear", "pull", 1024, 1024, 2001, 0.5, dtype, out_every=500)
+            _, samples = orc.run("shear", "pull", 16, 1024, 2001, 0.5, dtype, out_every=500)
         assert [orc.fmt(v) for v in samples] == want_text or np.allclose(
             [float(orc.fmt(v)) for v in samples], want, rtol=DECAY_RTOL_FMA)
 
