@@ -437,6 +437,13 @@ int fused_xcd_default()
     return e ? atoi(e) : 0;
 }
 int g_fused_xcd = fused_xcd_default();
+// LBM_FUSED_WALL_SPLIT=0: wall strips of small cavities keep the segment length of the other strips
+int fused_wall_split_default()
+{
+    const char *e = getenv("LBM_FUSED_WALL_SPLIT");
+    return e ? atoi(e) : 1;
+}
+int g_fused_wall_split = fused_wall_split_default();
 
 int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
@@ -459,6 +466,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
     uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 128);
+    bool small_grid = false;
     if (!g_fused_seg_rows) {
         // A wavefront walks seg + (rows of y halo) iterations one after the other, and the chip holds
         // `slots` wavefronts at a time.  Grids of many rounds use the measured segment length; smaller
@@ -468,6 +476,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         const uint64_t slots = 2048;   // 256 CUs x 4 SIMDs x 2 wavefronts
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
+            small_grid = true;
             uint64_t best = ~0ull;
             for (uint64_t s = 128; s >= 2; --s) {
                 const uint64_t waves = nstrips * ((rows + s - 1) / s);
@@ -480,13 +489,36 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const uint64_t nsegs = (rows + seg - 1) / seg;
     if (nstrips * nsegs > 0x7fffffffull)
         return fail(LBM_ERR_INVALID_ARGUMENT, "lattice too large for one fused launch");
+    // Cavities on grids of a round or two: the wavefronts of the two wall strips run the code with
+    // the wall cases in every iteration, about a fifth slower than the others (1024^2 fp32, four
+    // steps: 44 against 36 us per launch), and a small grid is over when its slowest wavefront is.
+    // They get segments short enough to finish with everyone else.
+    uint64_t seg_wall = 0, nsegs_wall = 0;
+    if (LID && small_grid && !g_fused_xcd && g_fused_wall_split) {
+        const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
+        const uint64_t iters = (seg + extra) * 5 / 6;          // iterations at 1.2 x the time each
+        const uint64_t slots = 2048, nwall = nstrips < 2 ? nstrips : 2;
+        const uint64_t rounds = (nstrips * nsegs + slots - 1) / slots;
+        // the shortest segments that do not push the grid into another round of wavefronts
+        for (uint64_t s = iters > extra + 2 ? iters - extra : 2; s < seg; ++s) {
+            const uint64_t nw = (rows + s - 1) / s;
+            if ((nstrips - nwall) * nsegs + nwall * nw <= rounds * slots) {
+                seg_wall = s;
+                nsegs_wall = nw;
+                break;
+            }
+        }
+    }
     lbm::FusedGeom g;
     g.nx = (uint32_t)nx; g.ny = (uint32_t)ny; g.y_lo = (uint32_t)y_lo; g.y_hi = (uint32_t)y_hi;
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
     g.xcd_map = g_fused_xcd;
+    g.seg_rows_wall = (uint32_t)seg_wall; g.nsegs_wall = (uint32_t)nsegs_wall;
     const uint64_t nsegs_grid = g.xcd_map ? (nsegs + 7) / 8 * 8 : nsegs;
-    const dim3 grid((unsigned)(nstrips * nsegs_grid)), block(lbm::kWave);
+    const uint64_t nwall = nstrips < 2 ? nstrips : 2;
+    const uint64_t blocks = nsegs_wall ? (nstrips - nwall) * nsegs + nwall * nsegs_wall : nstrips * nsegs_grid;
+    const dim3 grid((unsigned)blocks), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
         hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ROLLED>), grid, block, 0, stream, f, buf, g, om, df); \

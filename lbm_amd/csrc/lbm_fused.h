@@ -88,6 +88,9 @@ struct FusedGeom {
     int xcd_map;            // != 0: deal whole segments to the XCDs (see fused_body)
     int64_t y_goff;         // lid scenes: global row = row + y_goff
     uint64_t ny_glob;       //             cavity height
+    // lid scenes on small grids: the strips at the side walls run the slower code with the wall
+    // cases in every iteration, so they get shorter segments (0 = the same as everyone)
+    uint32_t seg_rows_wall, nsegs_wall;
 };
 
 // Value held by the lane below / above in the wavefront (DPP wave_shr:1 / wave_shl:1).  Lane 0 /
@@ -276,8 +279,23 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // j, j+8, ... and walks all strips of a segment in order, so halo lines are shared in one L2.
     // Measured at 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every
     // segment's strips instead): address-order dispatch is worth more than the shared lines.
-    uint32_t strip, seg;
-    if (g.xcd_map) {
+    uint32_t strip, seg, seg_rows = g.seg_rows, nsegs = g.nsegs;
+    if (LID && g.nsegs_wall != 0) {
+        // first the wall strips with their own (shorter) segments -- the slowest wavefronts start
+        // first --, then the strips without walls, segment by segment
+        const uint32_t nwall = g.nstrips < 2 ? g.nstrips : 2u, nmid = g.nstrips - nwall;
+        const uint32_t wall_blocks = nwall * g.nsegs_wall;
+        if (blockIdx.x < wall_blocks) {
+            strip = (blockIdx.x % nwall) ? g.nstrips - 1 : 0u;
+            seg = blockIdx.x / nwall;
+            seg_rows = g.seg_rows_wall;
+            nsegs = g.nsegs_wall;
+        } else {
+            const uint32_t b = blockIdx.x - wall_blocks;
+            strip = 1 + b % nmid;
+            seg = b / nmid;
+        }
+    } else if (g.xcd_map) {
         const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
         seg = (slot / g.nstrips) * 8 + xcd;
         strip = slot % g.nstrips;
@@ -285,7 +303,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         strip = blockIdx.x % g.nstrips;
         seg = blockIdx.x / g.nstrips;
     }
-    if (seg >= g.nsegs) return;
+    if (seg >= nsegs) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t nxv = g.nx / V;
     int64_t vx = (int64_t)strip * W - H + (int64_t)lane;
@@ -307,8 +325,8 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     const bool wall_wave = LID && __ballot(fl0.l || fl0.r) != 0;
     fl0.w = wall_wave;
 
-    const uint32_t ys = g.y_lo + seg * g.seg_rows;
-    const uint32_t ye = min(ys + g.seg_rows, g.y_hi);
+    const uint32_t ys = g.y_lo + seg * seg_rows;
+    const uint32_t ye = min(ys + seg_rows, g.y_hi);
     const uint32_t iters = (ye - ys) + D + NG;
     const size_t plane = (size_t)g.ny * g.nx;
 
