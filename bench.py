@@ -127,6 +127,12 @@ def pmc_traffic(workload_key):
 
 def main():
     args = parse()
+    # Libraries underneath (RCCL prints a version banner when its first communicator comes up) write to
+    # file descriptor 1; the one JSON line must be the only thing on stdout, so everything before it
+    # goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -284,7 +290,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, args.cpu_rows, args.cpu_seconds, args.precision,
                                                args.scheme, args.scene, args.omega)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if world > 1:
         dist.barrier()
