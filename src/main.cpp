@@ -262,37 +262,53 @@ struct Run {
     std::ofstream file;
     void *f = nullptr, *buf = nullptr, *vel = nullptr;
     std::vector<FLT> host;
+    double max_vel = 0;
     hipStream_t stream = nullptr;
     long long sweep_ns = 0;  // time spent in the steps alone (reported before the final line)
 };
 
-// output() of io.cpp:177-294
-static bool output(Run &r)
+// output() of io.cpp:177-294, in two halves so that the text of one sample is formatted while the
+// device already runs the next time steps: fetch_output brings the sample to the host (and waits for
+// it), emit_output formats and prints it.
+static void fetch_output(Run &r)
 {
     const Options &o = r.o;
     switch (o.output) {
-        case MAX_VEL: {
-            double m = 0;
-            die_lbm(lbm_max_velocity(r.f, kPrec, o.nx, o.ny, 0, o.ny, r.stream, &m), "max velocity");
-            char tmp[64];
-            fmt_g(tmp, sizeof tmp, (FLT)m);
-            (*r.out) << tmp << "," << std::flush;
-        } break;
-        case VEL_MAGS: {
+        case MAX_VEL:
+            die_lbm(lbm_max_velocity(r.f, kPrec, o.nx, o.ny, 0, o.ny, r.stream, &r.max_vel), "max velocity");
+            break;
+        case VEL_MAGS:
             die_lbm(lbm_velocity_magnitudes(r.f, r.vel, kPrec, o.nx, o.ny, 0, o.ny, r.stream), "velocity magnitudes");
             r.host.resize((size_t)o.nx * o.ny);
             die_hip(hipMemcpyAsync(r.host.data(), r.vel, r.host.size() * sizeof(FLT), hipMemcpyDeviceToHost, r.stream), "copy");
             die_hip(hipStreamSynchronize(r.stream), "sync");
-            if (!write_block(*r.out, r.host.data(), o.nx, o.ny, true)) return false;
-        } break;
-        case VEL_FIELD: {
+            break;
+        case VEL_FIELD:
             die_lbm(lbm_compute_velocities(r.f, r.vel, kPrec, o.nx, o.ny, 0, o.ny, r.stream), "velocities");
             r.host.resize((size_t)2 * o.nx * o.ny);
             die_hip(hipMemcpyAsync(r.host.data(), r.vel, r.host.size() * sizeof(FLT), hipMemcpyDeviceToHost, r.stream), "copy");
             die_hip(hipStreamSynchronize(r.stream), "sync");
+            break;
+        default: break;
+    }
+}
+
+static bool emit_output(Run &r)
+{
+    const Options &o = r.o;
+    switch (o.output) {
+        case MAX_VEL: {
+            char tmp[64];
+            fmt_g(tmp, sizeof tmp, (FLT)r.max_vel);
+            (*r.out) << tmp << "," << std::flush;
+        } break;
+        case VEL_MAGS:
+            if (!write_block(*r.out, r.host.data(), o.nx, o.ny, true)) return false;
+            break;
+        case VEL_FIELD:
             write_block(*r.out, r.host.data(), o.nx, o.ny, false);
             write_block(*r.out, r.host.data() + (size_t)o.nx * o.ny, o.nx, o.ny, false);
-        } break;
+            break;
         default: break;
     }
     return true;
@@ -321,9 +337,14 @@ static bool run_simulation(Run &r)
     // The reference's loop body is {output if due, one sweep, swap}.  Between two outputs the
     // iterations are handed to the library in runs of up to lbm_plan_steps(): same populations,
     // fewer passes over memory.
+    bool pending = false;      // a fetched sample waits to be printed
+    unsigned queued = 0;       // launches handed to the device since the sample was fetched
     for (UINT t = 0; t < o.steps;) {
         if (o.out_every > 0 && t % o.out_every == 0) {
-            if (!output(r)) return false;
+            if (pending && !emit_output(r)) return false;
+            fetch_output(r);
+            pending = true;
+            queued = 0;
         }
         UINT until = o.steps;
         if (o.out_every > 0) {
@@ -343,7 +364,14 @@ static bool run_simulation(Run &r)
         die_lbm(s, "sweep");
         std::swap(r.f, r.buf);
         t += (UINT)k;
+        // print the sample once the device has its work up to the next sample (or a good stretch
+        // of it) in its queue
+        if (pending && (t >= until || ++queued >= 64)) {
+            if (!emit_output(r)) return false;
+            pending = false;
+        }
     }
+    if (pending && !emit_output(r)) return false;
     die_hip(hipStreamSynchronize(r.stream), "sync");
     r.sweep_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now() - t0).count();
     return true;
