@@ -153,3 +153,23 @@ def test_unroll_loops_false_build_follows_the_rolled_spelling():
         orc.set_rolled(False)
     args = ("-nx", 24, "-ny", 16, "-w", 1.7, "-s", 41, "-of", 20, "-ovf", "-ld")
     assert run_main(*args).stdout == run_main(*args, exe="main_rolled").stdout
+
+
+@pytest.mark.gpu
+def test_double_precision_build(golden_dir):
+    """build/main_f64 is the driver compiled with USE_SINGLE_PRECISION=false (reference macros.h:5,
+    global.h:21-27): the whole config-1 series as the reference's own sources print it in fp64."""
+    import json
+    with open(os.path.join(golden_dir, "config1_series.json")) as fh:
+        gold = json.load(fh)
+    p = run_main("-nx", 1024, "-ny", 1024, "-w", 0.5, "-s", 50000, "-of", 500, "-omv", exe="main_f64")
+    assert p.stdout == gold["fp64_text"].rstrip(",") + ","
+    check_stderr_contract(p.stderr, 1024, 1024, 50000)
+    p = run_main("-ld", "-nx", 24, "-ny", 16, "-w", 1.7, "-s", 41, "-of", 20, "-ovf", exe="main_f64")
+    want = ""
+    for t in (0, 20, 40):
+        fr, _ = orc.run("lid", "push", 24, 16, t, 1.7, np.float64)
+        vel = orc.compute_velocities(fr)
+        for c in range(2):
+            want += "\n".join(",".join(orc.fmt(v) for v in r) for r in vel[c]) + "\n#\n"
+    assert p.stdout == want
