@@ -234,7 +234,8 @@ __device__ __forceinline__ void load_aos(T (&d)[9][V], const T *p)
         for (int j = 0; j < V; ++j) d[(k * V + j) % 9][(k * V + j) / 9] = v[j];
     }
 }
-// Plain stores: the nine accesses of a wavefront fill each line piecewise and must meet in the cache.
+// Plain stores: the nine accesses of a wavefront fill each line piecewise and must meet in the cache
+// (non-temporal ones write the pieces through: 16384^2 fp32, six steps, 270 -> 116 GLUPS).
 template <typename T, int V>
 __device__ __forceinline__ void store_aos(T *p, const T (&d)[9][V])
 {
