@@ -70,7 +70,10 @@
 namespace lbm {
 
 constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32 or 1 fp64 node
-constexpr int kFusedHaloBytes = 32;  // granule of the x halo on either side of a strip: stored lanes then cover whole 64-byte lines
+#ifndef LBM_FUSED_HALO_BYTES
+#define LBM_FUSED_HALO_BYTES 32
+#endif
+constexpr int kFusedHaloBytes = LBM_FUSED_HALO_BYTES;  // granule of the x halo on either side of a strip: stored lanes then cover whole 64-byte lines
 constexpr int kFusedMaxSteps = 6;    // more steps gain nothing (16384^2 fp32 pull K=6/7/8: 280/284/274 GLUPS, push
                                      // 279/265/236; fp64 pull 138/141/135, push 132/129/117)
 // halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules
