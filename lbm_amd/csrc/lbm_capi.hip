@@ -483,6 +483,16 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
                 const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
                 if (cost < best) { best = cost; seg = s; }
             }
+        } else if (seg == 128) {
+            // Larger grids: the same count, over the lengths at which a wavefront is as efficient
+            // as at 128 rows.  16384^2 in 128-row segments is 9.2 rounds, in 118-row ones 9.98:
+            // fp32 pull 296 -> 305 GLUPS, push 294 -> 301, cavity push 300 -> 309.
+            uint64_t best = ~0ull;
+            for (uint64_t s = 128; s >= 96; --s) {
+                const uint64_t waves = nstrips * ((rows + s - 1) / s);
+                const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
+                if (cost < best) { best = cost; seg = s; }
+            }
         }
     }
     if (seg > rows) seg = rows;
