@@ -473,7 +473,10 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         // ones pick the length that minimises rounds x iterations -- the tail round of a 2.4-round grid
         // is as expensive as a full one (fp32 pull, GLUPS before -> after: 512^2 38 -> 46, 2048^2
         // 137 -> 174, 4096^2 180 -> 224, 8192^2 231 -> 253; 1024^2 stays at 107, launch-gap-bound).
-        const uint64_t slots = 2048;   // 256 CUs x 4 SIMDs x 2 wavefronts
+        // 256 CUs x 4 SIMDs x 2 wavefronts.  A few kernels fit three per SIMD (fp32 push, three to
+        // five steps); counting those made their grids worse (1024^2 push 100 -> 80 GLUPS): a third
+        // wavefront shares the SIMD's issue slots, it does not add a slot's worth of speed.
+        const uint64_t slots = 2048;
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             small_grid = true;
