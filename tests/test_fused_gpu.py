@@ -48,7 +48,7 @@ def run_fused(scene, scheme, d_f, d_b, om, y_lo, y_hi, k, wrap_y=True, y_goff=0,
 # 56 fp64 nodes; 48 lanes for odd fp32 rows and for fp64 beyond four steps), the shortest supported
 # rows, odd lengths; heights: fewer rows than steps (multiple wraps), one segment, several segments
 SIZES = [(8, 3), (8, 1), (64, 48), (112, 9), (114, 7), (1024, 70), (2048, 5), (4, 6), (724, 33), (2, 5), (57, 6),
-         (229, 11), (3, 4), (1027, 9)]
+         (229, 11), (3, 4), (1027, 9), (8, 2), (2, 2), (113, 2)]   # the last three: lid and bottom wall on adjacent rows
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
