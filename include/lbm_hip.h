@@ -203,8 +203,20 @@ int lbm_velocity_magnitudes(const void *f, void *mag, int prec, uint64_t nx, uin
  * the library allocates on first use: two calls overlapping on one device race. */
 int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
                          uint64_t y_lo, uint64_t y_hi, void *stream);
-/* Same, result delivered to the host as double (exact widening of the FLT value).  Synchronises the
- * stream. */
+/* No counterpart in the reference.  lbm_max_velocity_dev for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same
+ * arguments, same kernels, same result, but the reduction's key lives in a 256-byte array that is part
+ * of the library's code object (one copy per device, held until the process ends) instead of a lazily
+ * hipMalloc'ed word, and the call makes no hipMalloc / hipFree.  The scratch need does not grow with
+ * the lattice, so the size limits are the ABI's own (extents up to 2^31-1 per axis, rejected with
+ * LBM_ERR_INVALID_ARGUMENT beyond).  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress): make that call outside a graph capture.  Every call on a device shares that
+ * device's array, which is cleared on `stream` at the start of each call: calls that overlap on one
+ * device (different streams or threads) race. */
+int lbm_max_velocity_dev_static(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
+                                uint64_t y_lo, uint64_t y_hi, void *stream);
+/* Same as lbm_max_velocity_dev, result delivered to the host as double (exact widening of the FLT
+ * value).  Synchronises the stream. */
 int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
                      uint64_t y_hi, void *stream, double *out_host);
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "lbm_compute_velocities": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
     "lbm_velocity_magnitudes": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
     "lbm_max_velocity_dev": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
+    "lbm_max_velocity_dev_static": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
     "lbm_max_velocity": (_int, [_ptr, _int, _u64, _u64, _u64, _u64, _ptr, C.POINTER(_dbl)]),
 }
 

@@ -795,13 +795,38 @@ int key_scratch(uint32_t **out)
     return LBM_OK;
 }
 
+// The reduction's scratch for callers that cannot allocate (lbm_max_velocity_dev_static): one
+// 256-byte line per device, part of the code object, so every device the library runs on holds its
+// own copy at its own address until the process ends.  `g_static_scratch` is only a host-side handle
+// of the symbol; device code and HIP calls get the per-device address resolved by static_scratch().
+constexpr size_t kStaticScratchBytes = 256;
+static __device__ __align__(256) uint32_t g_static_scratch[kStaticScratchBytes / sizeof(uint32_t)];
+uint32_t *g_static_scratch_ptr[kMaxDevices] = {};
+std::mutex g_static_scratch_mutex;
+
+int static_scratch(uint32_t **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(LBM_ERR_NO_DEVICE, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (g_static_scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+        if (p == nullptr || (uintptr_t)p % 256 != 0)
+            return fail(LBM_ERR_HIP, "static scratch of device %d resolved to %p", dev, p);
+        g_static_scratch_ptr[dev] = (uint32_t *)p;
+    }
+    *out = g_static_scratch_ptr[dev];
+    return LBM_OK;
+}
+
+// `key`: one zeroable word of device scratch (the first of `key_bytes` bytes that are cleared here)
 template <typename T>
 int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint64_t y_lo,
-                   uint64_t y_hi, hipStream_t stream)
+                   uint64_t y_hi, uint32_t *key, size_t key_bytes, hipStream_t stream)
 {
-    uint32_t *key = nullptr;
-    if (int s = key_scratch(&key)) return s;
-    HIP_TRY(hipMemsetAsync(key, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(key, 0, key_bytes, stream));
     if (y_lo < y_hi) {
         constexpr int B = 256;
         constexpr int V = vec_width<T>();
@@ -1046,9 +1071,28 @@ int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, ui
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
     if (out_dev == nullptr || (uintptr_t)out_dev % 8 != 0)
         return fail(LBM_ERR_INVALID_ARGUMENT, "result pointer must be non-null and 8-byte aligned");
+    uint32_t *key = nullptr;
+    if (int s = key_scratch(&key)) return s;
     hipStream_t st = (hipStream_t)stream;
-    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, st)
-                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, st);
+    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st)
+                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st);
+}
+
+int lbm_max_velocity_dev_static(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
+                                uint64_t y_lo, uint64_t y_hi, void *stream)
+{
+    if (int s = check_common(f, prec, nx, ny)) return s;
+    if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
+    if (out_dev == nullptr || (uintptr_t)out_dev % 8 != 0)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "result pointer must be non-null and 8-byte aligned");
+    // the reduction needs one key word whatever the lattice size; the static array holds one line
+    static_assert(kStaticScratchBytes >= sizeof(uint32_t), "static scratch smaller than the reduction's key");
+    uint32_t *key = nullptr;
+    if (int s = static_scratch(&key)) return s;
+    hipStream_t st = (hipStream_t)stream;
+    // the array keeps the previous call's key: the whole line is cleared on the stream first
+    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, key, kStaticScratchBytes, st)
+                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, key, kStaticScratchBytes, st);
 }
 
 int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
@@ -1062,8 +1106,8 @@ int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t
     // the decoded value goes to the second half of the scratch line
     void *res = (void *)((char *)key + 128);
     hipStream_t st = (hipStream_t)stream;
-    int s = prec == LBM_F32 ? max_velocity_t<float>(f, res, nx, ny, y_lo, y_hi, st)
-                            : max_velocity_t<double>(f, res, nx, ny, y_lo, y_hi, st);
+    int s = prec == LBM_F32 ? max_velocity_t<float>(f, res, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st)
+                            : max_velocity_t<double>(f, res, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st);
     if (s) return s;
     double host = 0;
     HIP_TRY(hipMemcpyAsync(&host, res, (size_t)prec, hipMemcpyDeviceToHost, st));
