@@ -25,6 +25,14 @@ The JSON line also carries
                 per node whatever the step count: `min_bytes_per_launch`), so `frac` can exceed 1;
                 `hbm_frac` prices the bytes actually moved (PMC `traffic` when a profile of this
                 workload is committed, else `min_bytes_per_launch`);
+                A second roof stands next to it for a fused launch, which is not bound by the
+                algorithmic bytes: `valu` = vector-ALU wave-instructions of the launch (PMC
+                SQ_INSTS_VALU of a committed profile) x 4 cycles / (1024 SIMDs x 2.4 GHz); `binding`
+                names the larger of the two floors and `frac_of_binding_roof` = that floor / the
+                measured launch time;
+  parity:       after the timed region every rank compares its rows with the CPU oracle's run of the
+                same global lattice (8 columns wide: the shear wave is x-invariant, so every column
+                of the GPU state must equal the oracle's column bit for bit);
   cpu_baseline: the CPU restatement of the reference algorithm (oracle/, OpenMP over rows) timed on
                 this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -40,6 +48,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, GB/s
+N_SIMDS = 256 * 4               # compute units x SIMDs
+CLOCK_HZ = 2.4e9                # peak engine clock
+VALU_CYCLES_PER_INST = 4        # issue cycles of one (packed) vector-ALU wave-instruction on one SIMD
 
 
 def parse():
@@ -58,9 +69,13 @@ def parse():
     ap.add_argument("--omega", type=float, default=0.5)
     ap.add_argument("--rolled", action="store_true",
                     help="the reference's UNROLL_LOOPS=false arithmetic in the periodic sweeps (shear scene)")
+    ap.add_argument("--arithmetic", choices=["unrolled", "contracted"], default="unrolled",
+                    help="contracted = the relaxation with explicit fused multiply-adds (LBM_ARITH_CONTRACTED); "
+                         "checked against the oracle's restatement of the same contraction")
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa",
                     help="aos = [NY][NX][9] arrays, the reference's COALESCING=false (single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the comparison with the CPU oracle after the run")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU-baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="exchange halos on the compute stream")
@@ -113,16 +128,37 @@ def cpu_baseline(nx, rows, budget_s, precision, scheme, scene, omega):
     }
 
 
-def pmc_traffic(workload_key):
-    """Per-launch HBM traffic measured with rocprofv3 PMC passes, if a summary for exactly this
-    workload has been committed under profiles/ (bench.py cannot collect counters itself)."""
+def pmc_profile(workload_key):
+    """Per-launch counters measured with rocprofv3 PMC passes (HBM bytes, vector-ALU instructions),
+    if a summary for exactly this workload and step count per launch has been committed under
+    profiles/ (bench.py cannot collect counters itself)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            table = json.load(fh)
-        return table.get(workload_key, {}).get("hbm_bytes_per_launch")
+            return json.load(fh).get(workload_key, {})
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def check_against_oracle(sim, scene, scheme, precision, nx, ny_glob, steps_total, omega, y_below, rows,
+                         arithmetic="unrolled"):
+    """The checker: rows [y_below, y_below + rows) of the oracle's run of the global lattice, 8
+    columns wide, against every column of this rank's rows.  Returns (checked, equal)."""
+    if scene != "shear":
+        return False, None     # the cavity is not x-invariant; covered by the test-suite instead
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    ndt = np.float32 if precision == "fp32" else np.float64
+    with orc.arithmetic(arithmetic):
+        want, _ = orc.run("shear", scheme, 8, ny_glob, steps_total, omega, ndt)
+    col = torch.from_numpy(np.ascontiguousarray(want[:, y_below:y_below + rows, :1])).to(sim.f.device)
+    mine = sim.interior() if hasattr(sim, "interior") else sim.f
+    if mine.dim() == 3 and mine.shape[0] != 9:          # [NY, NX, 9] arrays
+        mine = mine.permute(2, 0, 1)
+    bits = torch.int32 if precision == "fp32" else torch.int64
+    equal = bool((mine.contiguous().view(bits) == col.view(bits)).all())
+    return True, equal
 
 
 def main():
@@ -175,6 +211,10 @@ def main():
 
     if args.rolled:
         ops.set_unroll_loops(False)
+    if args.arithmetic == "contracted":
+        if args.rolled or args.layout == "aos":
+            raise SystemExit("--arithmetic contracted goes with neither --rolled nor --layout aos")
+        ops.set_arithmetic("contracted")
     if args.layout == "aos":
         if world != 1 or args.slab:
             raise SystemExit("--layout aos runs on one GPU without the slab path")
@@ -198,19 +238,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    launches = lambda: sim.launches if hasattr(sim, "launches") else sim.blocks
+    # The launch plan of the timed run: one entry per sweep launch (single device) or block (slabs).
+    def plan_of(n):
+        probe_rows = ny_loc
+        out, kmax = [], (sim.G if hasattr(sim, "G") else None)
+        while n > 0:
+            if kmax is None:
+                k = ops.plan_steps(sim.f, probe_rows, n)
+            else:
+                k = -(-n // -(-n // kmax))
+            out.append(k)
+            n -= k
+        return out
+
+    plan = plan_of(args.steps)
+    # Warm-up: the W steps asked for, then one launch of every step count of the timed plan that the
+    # warm-up did not already run (the first launch of a kernel pays for loading its code).
     sim.step(args.warmup)
-    launches0 = launches()
+    warmed = set(sim.launch_steps)
+    extra_warmup = 0
+    for k in sorted(set(plan) - warmed):
+        sim.step(k)
+        extra_warmup += k
     stream = torch.cuda.current_stream(device)  # the stream the sweeps are launched on
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(plan) + 1)]
     sync()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    sim.step(args.steps)
-    ev1.record(stream)
+    marks[0].record(stream)
+    for i, k in enumerate(plan):
+        sim.step(k)
+        marks[i + 1].record(stream)
     sync()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    assert sim.launch_steps[-len(plan):] == plan, (sim.launch_steps[-len(plan):], plan)
+    launch_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(plan))]
+    steps_total = args.warmup + extra_warmup + args.steps
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -222,25 +284,51 @@ def main():
     if not (0.0 <= vmax < 1.0):
         raise SystemExit(f"benchmark state is not physical: max |u| = {vmax}")
 
+    # parity: every rank checks its own rows against the oracle's run of the global lattice
+    if hasattr(sim, "y_below"):
+        my_below, my_rows = sim.y_below, sim.n
+    else:
+        my_below, my_rows = 0, ny_loc
+    checked, equal = check_against_oracle(sim, args.scene, args.scheme, args.precision, nx, ny_glob,
+                                          steps_total, args.omega, my_below, my_rows, args.arithmetic) \
+        if (not args.rolled and not args.no_parity) else (False, None)
+    report = {"rank": rank, "device": f"cuda:{dev_index}", "name": torch.cuda.get_device_name(dev_index),
+              "rows": [my_below, my_below + my_rows], "parity_checked": checked, "bit_identical": equal}
+    if world > 1:
+        reports = [None] * world
+        dist.all_gather_object(reports, report)
+    else:
+        reports = [report]
+    if any(r["parity_checked"] and not r["bit_identical"] for r in reports):
+        raise SystemExit(f"benchmark state differs from the CPU oracle: {reports}")
+
     if rank == 0:
         updates = nx * ny_glob * args.steps
         mlups = updates / elapsed / 1e6
-        # dominant kernel = the (interior) sweep: one launch per run of up to six time steps
-        n_launch = launches() - launches0
+        # dominant kernel = the (interior) sweep at the step count most launches of the plan take
+        n_launch = len(plan)
+        k_dom = max(set(plan), key=lambda k: (plan.count(k), k))
+        dom_ms = [ms for ms, k in zip(launch_ms, plan) if k == k_dom]
+        launch_s = sum(dom_ms) / len(dom_ms) * 1e-3
         steps_per_launch = args.steps / n_launch
-        launch_s = dev_ms * 1e-3 / n_launch
-        alg_bytes = nx * ny_loc * bytes_per_node * steps_per_launch
+        alg_bytes = nx * ny_loc * bytes_per_node * k_dom
         min_bytes = nx * ny_loc * bytes_per_node
         achieved = alg_bytes / launch_s / 1e9
         workload = (f"{'shear-wave decay' if args.scene == 'shear' else 'lid-driven cavity'} "
                     f"{nx}x{ny_glob} {args.precision} {args.scheme}")
-        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "") + ("-rolled" if args.rolled else "")
-        # profiles are keyed by the step count of the dominant launches (a run whose length is not a
-        # multiple of it ends with one shorter launch)
-        k_dom = min(args.steps, -(-args.steps // n_launch))
+        key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "") + ("-rolled" if args.rolled else "") + ("-contracted" if args.arithmetic == "contracted" else "")
+        # profiles are keyed by the step count of the dominant launches
         if k_dom != 1:
             key += f"-fused{k_dom}"
-        traffic = pmc_traffic(key) if world == 1 else None
+        prof = pmc_profile(key) if world == 1 and not args.slab else {}
+        traffic = prof.get("hbm_bytes_per_launch")
+        valu_insts = prof.get("valu_insts_per_launch")
+        hbm_floor_s = (traffic if traffic else min_bytes) / (HBM_PEAK_GBS * 1e9)
+        valu_floor_s = valu_insts * VALU_CYCLES_PER_INST / (N_SIMDS * CLOCK_HZ) if valu_insts else None
+        floors = {"hbm": hbm_floor_s}
+        if valu_floor_s:
+            floors["valu"] = valu_floor_s
+        binding = max(floors, key=floors.get)
         out = {
             "metric": "MLUPS",
             "value": mlups,
@@ -257,12 +345,14 @@ def main():
             "config": {
                 "workload": workload,
                 "scene": args.scene, "scheme": args.scheme, "layout": args.layout,
-                "arithmetic": "rolled loops (UNROLL_LOOPS=false)" if args.rolled else "unrolled", "nx": nx, "ny_global": ny_glob,
+                "arithmetic": "rolled loops (UNROLL_LOOPS=false)" if args.rolled else args.arithmetic, "nx": nx, "ny_global": ny_glob,
                 "ny_per_gpu": ny_loc, "omega": args.omega,
                 "decomposition": ("single device" if world == 1 and not args.slab else
                                   f"{world} y-slab(s), {sim.G} ghost row(s) per edge refreshed every "
                                   f"{sim.G} step(s), RCCL send/recv"),
                 "steps_per_launch": steps_per_launch,
+                "launch_plan": plan,
+                "warmup_steps_run": args.warmup + extra_warmup,
                 "roofline_mlups_per_gpu": HBM_PEAK_GBS * 1e3 / bytes_per_node,
                 "frac_of_roofline_whole_job": mlups / (world * HBM_PEAK_GBS * 1e3 / bytes_per_node),
                 "max_velocity_after_run": vmax,
@@ -276,10 +366,20 @@ def main():
                 "traffic": traffic,
                 "kernel": (f"{args.scheme} {'periodic' if args.scene == 'shear' else 'lid-driven'} sweep, "
                            f"{k_dom} time step(s) per launch"),
-                "steps_per_launch": steps_per_launch,
+                "steps_per_launch": k_dom,
+                "launches_timed": len(dom_ms),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "min_bytes_per_launch": min_bytes,
-                "hbm_frac": (traffic if traffic else min_bytes) / launch_s / 1e9 / HBM_PEAK_GBS,
+                "hbm_frac": hbm_floor_s / launch_s,
+                "hbm_bytes_source": "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of a committed profile" if traffic
+                                    else "compulsory bytes (no profile of this workload committed)",
+                "valu": ({"insts_per_launch": valu_insts, "cycles_per_inst": VALU_CYCLES_PER_INST,
+                          "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "floor_ms": valu_floor_s * 1e3,
+                          "frac": valu_floor_s / launch_s} if valu_floor_s else None),
+                "valu_frac": (valu_floor_s / launch_s) if valu_floor_s else None,
+                "binding": binding,
+                "frac_of_binding_roof": floors[binding] / launch_s,
+                "profile": prof.get("source"),
                 "launch_ms": launch_s * 1e3,
                 "note": ("one launch advances several time steps per pass over HBM, so the algorithmic rate "
                          "(72/144 B per node and step) can exceed the HBM peak; hbm_frac prices the bytes "
@@ -287,6 +387,12 @@ def main():
                         "one time step per launch",
             },
         }
+        out["parity_checked"] = all(r["parity_checked"] for r in reports)
+        out["parity"] = {"against": "CPU oracle, 8-column run of the global lattice, every column bit for bit",
+                         "steps_compared": steps_total, "ranks": reports}
+        out["world"] = {"size": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
+                        "transport": ("RCCL" if dist.is_initialized() and dist.get_backend() == "nccl"
+                                      else (dist.get_backend() if dist.is_initialized() else "none"))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, args.cpu_rows, args.cpu_seconds, args.precision,
                                                args.scheme, args.scene, args.omega)

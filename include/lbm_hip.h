@@ -72,6 +72,27 @@ int lbm_get_layout(void);
 int lbm_set_unroll_loops(int unrolled);
 int lbm_get_unroll_loops(void);
 
+/* Spelling of the BGK relaxation, process-wide (a superset of lbm_set_unroll_loops):
+ *   LBM_ARITH_UNROLLED    pull_periodic / push_periodic / push_lid_driven as written
+ *                         (pull-push.cpp:25-72, :138-185, :454-483), every operation rounded where the
+ *                         source text puts it; the default.
+ *   LBM_ARITH_ROLLED      the *_for functions (pull-push.cpp:77-120, :190-243) = lbm_set_unroll_loops(0).
+ *   LBM_ARITH_CONTRACTED  the unrolled spelling with the multiply-adds fused that a compiler may fuse
+ *                         under the reference's own build flags (-O3 -march=native, CMakeLists.txt:18;
+ *                         nvcc and hipcc contract by default): ux*ux+uy*uy, 1 -+ 3a, + (4.5a)a,
+ *                         w*(...) - f and f + om*(...) each become one fused multiply-add; sums, the
+ *                         reciprocal of the density (correctly rounded) and all other products are
+ *                         unchanged.  A third fewer vector instructions per node, and up to eight
+ *                         time steps per *_fused call.  Populations stay within the parity budget of
+ *                         the unrolled spelling (fp32 1e-5, fp64 1e-12 max-abs over thousands of
+ *                         steps; measured 2e-7 / 1e-15).  All sweeps on [9][NY][NX] arrays; the
+ *                         one-step entry points run element-wise kernels.  fp32 rows must have an even
+ *                         length >= 4 for the *_fused entry points.
+ * The environment variable LBM_ARITHMETIC (unrolled | rolled | contracted) sets the initial value. */
+enum { LBM_ARITH_UNROLLED = 0, LBM_ARITH_ROLLED = 1, LBM_ARITH_CONTRACTED = 2 };
+int lbm_set_arithmetic(int arithmetic);
+int lbm_get_arithmetic(void);
+
 /* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
  * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (64, 128, 256 or 512) and the
  * cap on resident waves per compute unit for the sweep kernels (1..32; the sweeps stream fastest
@@ -159,13 +180,14 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * Returns LBM_ERR_UNSUPPORTED (nothing launched) for rows of a single node; callers then take
  * nsteps one-step sweeps. */
 
-/* Largest nsteps the fused entry points accept for this precision and row length: 6, or 1 when
- * the row length is unsupported. */
+/* Largest nsteps the fused entry points accept for this precision and row length: 6 (8 with
+ * LBM_ARITH_CONTRACTED), or 1 when the row length is unsupported. */
 int lbm_fused_max_steps(int prec, uint64_t nx);
 
 /* How many of the `remaining` iterations of the time loop the next call should take for a lattice
- * of `rows` rows of nx nodes: lbm_fused_max_steps() (1 for row lengths the fused sweeps do not
- * support), never more than `remaining`.  Environment: LBM_FUSED_MAX_STEPS caps the answer,
+ * of `rows` rows of nx nodes: the run is cut into the fewest launches of at most
+ * lbm_fused_max_steps() steps (fewer on small lattices; 1 for row lengths the fused sweeps do not
+ * support) and those launches are made as equal as possible (20 remaining -> 5, then 5, 5, 5).  Environment: LBM_FUSED_MAX_STEPS caps the answer,
  * LBM_FUSED_MIN_NODES makes lattices below that many nodes take one step per launch.  The time loops of this library's drivers (main.cpp:64-83) ask this before
  * every launch. */
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining);
@@ -219,6 +241,15 @@ int lbm_max_velocity_dev_static(const void *f, void *out_dev, int prec, uint64_t
  * value).  Synchronises the stream. */
 int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
                      uint64_t y_hi, void *stream, double *out_host);
+
+/* ---------------------------------------------------------------- self-check --------------- */
+
+/* No counterpart in the reference.  out[i] = the reciprocal of x[i] exactly as LBM_ARITH_CONTRACTED
+ * forms 1/rho (pull-push.cpp:27): in fp32 a hardware reciprocal estimate and one fused Newton step,
+ * which must equal the correctly rounded IEEE quotient 1.0f / x[i] for every normal x; in fp64 the
+ * IEEE division itself.  x and out are device arrays of n FLT.  The test-suite runs it over every
+ * fp32 value of three binades. */
+int lbm_selftest_reciprocal(const void *x, void *out, int prec, uint64_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,8 @@ SIGNATURES = {
     "lbm_get_layout": (_int, []),
     "lbm_set_unroll_loops": (_int, [_int]),
     "lbm_get_unroll_loops": (_int, []),
+    "lbm_set_arithmetic": (_int, [_int]),
+    "lbm_get_arithmetic": (_int, []),
     "lbm_set_launch_shape": (_int, [_uint, _uint]),
     "lbm_init_shearwave": (_int, [_ptr, _int, _u64, _u64, _dbl, _dbl, _u64, _u64, _uint, _ptr]),
     "lbm_init_rest": (_int, [_ptr, _int, _u64, _u64, _dbl, _ptr]),
@@ -51,6 +53,7 @@ SIGNATURES = {
     "lbm_max_velocity_dev": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
     "lbm_max_velocity_dev_static": (_int, [_ptr, _ptr, _int, _u64, _u64, _u64, _u64, _ptr]),
     "lbm_max_velocity": (_int, [_ptr, _int, _u64, _u64, _u64, _u64, _ptr, C.POINTER(_dbl)]),
+    "lbm_selftest_reciprocal": (_int, [_ptr, _ptr, _int, _u64, _ptr]),
 }
 
 _lib = None

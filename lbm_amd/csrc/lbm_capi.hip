@@ -45,9 +45,16 @@ int fail(int status, const char *fmt, ...)
 // memory layout of every distribution array passed in (lbm_set_layout)
 int g_layout = LBM_LAYOUT_SOA;
 
-// 0: the unrolled spelling of the relaxation (default), 1: the reference's UNROLL_LOOPS=false
-// spelling (periodic sweeps only; lbm_set_unroll_loops)
-int g_rolled = 0;
+// spelling of the relaxation (lbm_set_arithmetic / lbm_set_unroll_loops): lbm::kArithUnrolled (default),
+// kArithRolled (the reference's UNROLL_LOOPS=false spelling; periodic sweeps only) or kArithContracted
+int arithmetic_default()
+{
+    const char *e = getenv("LBM_ARITHMETIC");
+    if (e && strcmp(e, "contracted") == 0) return lbm::kArithContracted;
+    if (e && strcmp(e, "rolled") == 0) return lbm::kArithRolled;
+    return lbm::kArithUnrolled;
+}
+int g_arith = arithmetic_default();
 
 // launch-shape hint (lbm_set_launch_shape)
 unsigned g_threads_x = 0;
@@ -79,6 +86,7 @@ int xcd_rows_default()
 }
 int g_xcd_rows = xcd_rows_default();
 
+constexpr int kMaxDevicesForProps = 64;
 constexpr uint64_t kMaxExtent = 0x7fffffffull;  // extents are 32-bit inside the kernels
 
 int check_common(const void *f, int prec, uint64_t nx, uint64_t ny)
@@ -218,15 +226,21 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
     constexpr int V = vec_width<T>();
     const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, wrap_y);
     const uint64_t rows = y_hi - y_lo;
-    if (g_rolled) {
-        // the rolled arithmetic lives in the element-wise kernel and in the multi-step kernels
+    if (g_arith != lbm::kArithUnrolled) {
+        // the other spellings live in the element-wise kernel and in the multi-step kernels
         const unsigned block = pick_block(nx);
         const dim3 grid = sweep_grid(nx, block, rows);
         constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
-        LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, true>), grid, dim3(B), 0, stream, f, buf, g,
-                               0u, (uint32_t)nx, 1, om, (T)0))
-        return launch_status(PULL ? "pull periodic (rolled)" : "push periodic (rolled)");
+        if (g_arith == lbm::kArithRolled) {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithRolled>), grid, dim3(B), 0, stream, f, buf, g,
+                                   0u, (uint32_t)nx, 1, om, (T)0))
+        } else {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, f, buf, g,
+                                   0u, (uint32_t)nx, 1, om, (T)0))
+        }
+        return launch_status(PULL ? "pull periodic (element-wise)" : "push periodic (element-wise)");
     }
     if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
@@ -277,14 +291,20 @@ int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     if (LX >= HX || LY >= HY) return LBM_OK;
     const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
     constexpr int V = vec_width<T>();
-    if (g_rolled) {
+    if (g_arith != lbm::kArithUnrolled) {
         const unsigned block = pick_block(HX - LX);
         const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
         constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
-        LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, true>), grid, dim3(B), 0, stream, (const T *)f_,
-                               (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
-        return launch_status("periodic inner (rolled)");
+        if (g_arith == lbm::kArithRolled) {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithRolled>), grid, dim3(B), 0, stream, (const T *)f_,
+                                   (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
+        } else {
+            LBM_FOR_BLOCK(block,
+                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, (const T *)f_,
+                                   (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
+        }
+        return launch_status("periodic inner (element-wise)");
     }
     if (PULL && HX - LX >= 4 * (uint64_t)V) {
         const uint64_t lanes = (HX - LX + V - 1) / V;
@@ -327,8 +347,11 @@ int sweep_outer(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
 {
     const uint64_t lanes = (nx - 2) + (ny - 4);
     constexpr int B = 256;
-    if (g_rolled)
-        hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, true>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
+    if (g_arith == lbm::kArithRolled)
+        hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, lbm::kArithRolled>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
+                           stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
+    else if (g_arith == lbm::kArithContracted)
+        hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, lbm::kArithContracted>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
                            stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
     else
         hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
@@ -365,7 +388,15 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
     constexpr int V = vec_width<T>();
     const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, 0, y_goff, ny_glob);
     const uint64_t rows = y_hi - y_lo;
-    if (nx % V == 0 && nx >= 2 * V) {
+    if (g_arith == lbm::kArithContracted) {
+        // the contracted spelling lives in the element-wise kernel and in the multi-step kernels
+        const unsigned block = pick_block(nx);
+        const dim3 grid = sweep_grid(nx, block, rows);
+        constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
+        LBM_FOR_BLOCK(block,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, f, buf, g,
+                               0u, (uint32_t)nx, 0, om, df))
+    } else if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
@@ -445,7 +476,25 @@ int fused_wall_split_default()
 }
 int g_fused_wall_split = fused_wall_split_default();
 
-int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
+int max_fused_steps(int /*prec*/)
+{
+    return g_arith == lbm::kArithContracted ? lbm::kFusedMaxStepsContracted : lbm::kFusedMaxSteps;
+}
+
+// Wavefronts the device holds at once at two per SIMD (the residency of every multi-step kernel):
+// compute units x 4 SIMDs x 2.  2048 on a whole MI355X; a partition (CPX, DPX) has fewer units.
+uint64_t wave_slots()
+{
+    static uint64_t slots[kMaxDevicesForProps] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesForProps) return 2048;
+    if (slots[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots[dev] = (uint64_t)cus * 8;
+    }
+    return slots[dev];
+}
 
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
 
@@ -457,11 +506,13 @@ bool fused_supported(uint64_t nx)
     return nx >= 2;
 }
 
-template <typename T, int V, bool PUSH, bool LID, bool AOS, bool ROLLED = false>
+template <typename T, int V, bool PUSH, bool LID, bool AOS, int ARITH = lbm::kArithUnrolled>
 int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint64_t y_lo, uint64_t y_hi,
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
     // lanes stored per strip: 56, or 48 for fp64 beyond four steps (wider x halo)
+    static_assert(lbm::fused_halo_lanes<T, V, 5>() == lbm::fused_halo_lanes<T, V, lbm::kFusedMaxStepsContracted>(),
+                  "one halo width for every step count above four");
     const uint64_t W = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>() : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
@@ -473,10 +524,10 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         // ones pick the length that minimises rounds x iterations -- the tail round of a 2.4-round grid
         // is as expensive as a full one (fp32 pull, GLUPS before -> after: 512^2 38 -> 46, 2048^2
         // 137 -> 174, 4096^2 180 -> 224, 8192^2 231 -> 253; 1024^2 stays at 107, launch-gap-bound).
-        // 256 CUs x 4 SIMDs x 2 wavefronts.  A few kernels fit three per SIMD (fp32 push, three to
+        // Slots: two wavefronts per SIMD.  A few kernels fit three per SIMD (fp32 push, three to
         // five steps); counting those made their grids worse (1024^2 push 100 -> 80 GLUPS): a third
         // wavefront shares the SIMD's issue slots, it does not add a slot's worth of speed.
-        const uint64_t slots = 2048;
+        const uint64_t slots = wave_slots();
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             small_grid = true;
@@ -510,7 +561,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     if (LID && small_grid && !g_fused_xcd && g_fused_wall_split) {
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         const uint64_t iters = (seg + extra) * 5 / 6;          // iterations at 1.2 x the time each
-        const uint64_t slots = 2048, nwall = nstrips < 2 ? nstrips : 2;
+        const uint64_t slots = wave_slots(), nwall = nstrips < 2 ? nstrips : 2;
         const uint64_t rounds = (nstrips * nsegs + slots - 1) / slots;
         // the shortest segments that do not push the grid into another round of wavefronts
         for (uint64_t s = iters > extra + 2 ? iters - extra : 2; s < seg; ++s) {
@@ -534,8 +585,17 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const dim3 grid((unsigned)blocks), block(lbm::kWave);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK:                                                                                                     \
-        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ROLLED>), grid, block, 0, stream, f, buf, g, om, df); \
+        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>), grid, block, 0, stream, f, buf, g, om, df); \
         break;
+    if constexpr (ARITH == lbm::kArithContracted) {
+        // fewer vector instructions per step: more steps per pass over memory pay
+        switch (k) {
+            LBM_FUSED_CASE(7)
+            LBM_FUSED_CASE(8)
+            default: break;
+        }
+        if (k == 7 || k == 8) return launch_status("fused sweep");
+    }
     switch (k) {
         LBM_FUSED_CASE(1)
         LBM_FUSED_CASE(2)
@@ -543,7 +603,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         LBM_FUSED_CASE(4)
         LBM_FUSED_CASE(5)
         LBM_FUSED_CASE(6)
-        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, lbm::kFusedMaxSteps);
+        default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, max_fused_steps(0));
     }
 #undef LBM_FUSED_CASE
     return launch_status("fused sweep");
@@ -563,15 +623,24 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
     const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8);
     if constexpr (!LID) {
-        if (g_rolled) {
+        if (g_arith == lbm::kArithRolled) {
             if (g_layout == LBM_LAYOUT_AOS)
                 return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
             if (narrow)
                 return fail(LBM_ERR_UNSUPPORTED,
                             "the rolled arithmetic takes several steps per call only for fp32 rows of an even length >= 4 (nx=%llu)",
                             (unsigned long long)nx);
-            return launch_fused<T, V8, PUSH, false, false, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
+            return launch_fused<T, V8, PUSH, false, false, lbm::kArithRolled>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
         }
+    }
+    if (g_arith == lbm::kArithContracted) {
+        if (g_layout == LBM_LAYOUT_AOS)
+            return fail(LBM_ERR_UNSUPPORTED, "the contracted arithmetic is not available on [NY][NX][9] arrays");
+        if (narrow)
+            return fail(LBM_ERR_UNSUPPORTED,
+                        "the contracted arithmetic takes several steps per call only for fp32 rows of an even length >= 4 (nx=%llu)",
+                        (unsigned long long)nx);
+        return launch_fused<T, V8, PUSH, LID, false, lbm::kArithContracted>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
     }
     if (g_layout == LBM_LAYOUT_AOS) {
         if constexpr (V8 > 1) {
@@ -597,7 +666,8 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
     const bool supported = lbm_fused_max_steps(prec, nx) > 1;
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
     // length the fused kernels cannot take
-    if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
+    if (k == 1 && g_layout == LBM_LAYOUT_SOA &&
+        (!supported || (wrap_y && y_lo == 0 && y_hi == ny && g_arith != lbm::kArithContracted)))
         return periodic_rows<PULL>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
     if (!wrap_y && y_lo < y_hi && (y_lo < (uint64_t)k || y_hi + (uint64_t)k > ny))
@@ -606,7 +676,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
                     k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
     if (!supported)
         return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes%s (nx=%llu)",
-                    g_rolled ? ", and an even number of fp32 nodes with the rolled arithmetic" : "",
+                    g_arith != lbm::kArithUnrolled ? ", and an even number of fp32 nodes with the rolled or contracted arithmetic" : "",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -625,7 +695,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
     {
         const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
         const bool whole = y_lo == 0 && y_hi == ny && y_goff == 0 && ny_glob == ny;
-        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || whole))
+        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || (whole && g_arith != lbm::kArithContracted)))
             return lid_rows<PULL>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
     }
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
@@ -666,8 +736,8 @@ int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, d
     if (nx < 2)
         return fail(LBM_ERR_UNSUPPORTED, "[NY][NX][9] arrays need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
-    if (!LID && g_rolled)
-        return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
+    if ((!LID && g_arith == lbm::kArithRolled) || g_arith == lbm::kArithContracted)
+        return fail(LBM_ERR_UNSUPPORTED, "the rolled and contracted arithmetics are not available on [NY][NX][9] arrays");
     const bool whole = y_lo == 0 && y_hi == ny && (LID ? (y_goff == 0 && ny_glob == ny) : wrap_y != 0);
     if (!PULL && !whole)
         return fail(LBM_ERR_UNSUPPORTED,
@@ -890,11 +960,21 @@ int lbm_get_layout(void) { return g_layout; }
 
 int lbm_set_unroll_loops(int unrolled)
 {
-    g_rolled = unrolled ? 0 : 1;
+    g_arith = unrolled ? lbm::kArithUnrolled : lbm::kArithRolled;
     return LBM_OK;
 }
 
-int lbm_get_unroll_loops(void) { return g_rolled ? 0 : 1; }
+int lbm_get_unroll_loops(void) { return g_arith == lbm::kArithRolled ? 0 : 1; }
+
+int lbm_set_arithmetic(int arithmetic)
+{
+    if (arithmetic != LBM_ARITH_UNROLLED && arithmetic != LBM_ARITH_ROLLED && arithmetic != LBM_ARITH_CONTRACTED)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", arithmetic);
+    g_arith = arithmetic;
+    return LBM_OK;
+}
+
+int lbm_get_arithmetic(void) { return g_arith; }
 
 int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu)
 {
@@ -991,7 +1071,7 @@ int lbm_fused_max_steps(int prec, uint64_t nx)
     if (prec != LBM_F32 && prec != LBM_F64) return 0;
     bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
     // the rolled arithmetic is built for 8-byte lanes only, and not for [NY][NX][9] arrays
-    if (g_rolled && (g_layout == LBM_LAYOUT_AOS || (prec == LBM_F32 && (nx % 2 != 0 || nx < 4)))) ok = false;
+    if (g_arith != lbm::kArithUnrolled && (g_layout == LBM_LAYOUT_AOS || (prec == LBM_F32 && (nx % 2 != 0 || nx < 4)))) ok = false;
     return ok ? max_fused_steps(prec) : 1;
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
@@ -1017,7 +1097,11 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     uint64_t k = m ? strtoull(m, nullptr, 10) : dflt;
     if (k < 1) k = 1;
     if (k > (uint64_t)kmax) k = (uint64_t)kmax;
-    return (int)(remaining < k ? remaining : k);
+    // The run is cut into the fewest launches of at most k steps, and those launches are made as
+    // equal as possible: 20 steps are 5+5+5+5, not 6+6+6+2 -- a short tail launch pays a whole pass
+    // over memory for its few steps (16384^2 fp32: two steps per launch run at half the rate of six).
+    const uint64_t launches = (remaining + k - 1) / k;
+    return (int)((remaining + launches - 1) / launches);
 }
 int lbm_pull_periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om,
                             uint64_t y_lo, uint64_t y_hi, int wrap_y, int nsteps, void *stream)
@@ -1120,6 +1204,20 @@ int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t
         *out_host = host;
     }
     return LBM_OK;
+}
+
+int lbm_selftest_reciprocal(const void *x, void *out, int prec, uint64_t n, void *stream)
+{
+    if (prec != LBM_F32 && prec != LBM_F64) return fail(LBM_ERR_INVALID_ARGUMENT, "precision tag %d is neither 4 nor 8", prec);
+    if (n == 0) return LBM_OK;
+    if (x == nullptr || out == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null pointer");
+    const uint64_t blocks = (n + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536)), block(256);
+    if (prec == LBM_F32)
+        hipLaunchKernelGGL((lbm::k_reciprocal<float>), grid, block, 0, (hipStream_t)stream, (const float *)x, (float *)out, n);
+    else
+        hipLaunchKernelGGL((lbm::k_reciprocal<double>), grid, block, 0, (hipStream_t)stream, (const double *)x, (double *)out, n);
+    return launch_status("reciprocal self-check");
 }
 
 }  // extern "C"

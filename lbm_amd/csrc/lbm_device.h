@@ -202,18 +202,104 @@ __device__ __forceinline__ void collide_for_x(const X f_0, const X f_1, const X 
     }
 }
 
-template <typename T, bool ROLLED = false>
+// Spellings of the relaxation (template parameter ARITH of everything below).
+constexpr int kArithUnrolled = 0;     // collide_x: pull_periodic / push_periodic / push_lid_driven
+constexpr int kArithRolled = 1;       // collide_for_x: the *_for functions (periodic sweeps only)
+constexpr int kArithContracted = 2;   // collide_fma_x: explicit fused multiply-adds (all sweeps)
+
+// 1/x for fp32, correctly rounded like the IEEE division it stands for, in three instructions
+// instead of the eleven of the division sequence: v_rcp_f32 is good to one ulp, and one Newton step
+// in fused arithmetic, r + r*(1 - x*r), then rounds correctly (Markstein's theorem; checked
+// exhaustively on the device over every fp32 in [0.5, 4): tests/test_contracted_gpu.py).  Valid
+// while x and 1/x are normal numbers (2^-126 <= |x| <= 2^126): densities of any physical state.
+__device__ __forceinline__ float recip_exact(const float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+template <typename X, typename T>
+__device__ __forceinline__ X recip_x(const X x)
+{
+    if constexpr (sizeof(T) == 8) {
+        return X(T(1.0)) / x;
+    } else if constexpr (sizeof(X) == sizeof(T)) {
+        return X(recip_exact(x));
+    } else {
+        X r;
+        r.x = recip_exact(x.x);
+        r.y = recip_exact(x.y);
+        return r;
+    }
+}
+
+// One contraction of collide_x that a compiler may apply to the reference's text (the reference is
+// built -O3 -march=native, CMakeLists.txt:18, where a*b+c may fuse; which ones do differs from build
+// to build).  This spelling fixes one choice with explicit fused multiply-adds, so it does not depend
+// on compiler flags and the CPU checker can restate it operation by operation:
+//     ux*ux + uy*uy -> fma(ux, ux, uy*uy)          1 -+ 3*a        -> fma(-+3, a, 1)
+//     ... + (f45*a)*a -> fma(f45*a, a, ...)        (w*bracket) - f -> fma(w, bracket, -f)
+//     f + om*(...)  -> fma(om, ..., f)
+// Sums, the reciprocal of the density and all other products round as in collide_x.  A third fewer
+// vector instructions per node; populations stay within 1e-6 (fp32) / 1e-15 (fp64) of collide_x's
+// over thousands of steps.
+template <typename X, typename T>
+__device__ __forceinline__ void collide_fma_x(const X f_0, const X f_1, const X f_2, const X f_3,
+                                              const X f_4, const X f_5, const X f_6, const X f_7,
+                                              const X f_8, const T om_, X (&o)[9])
+{
+    const X om = X(om_);
+    const X rho = f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8;
+    const X rho_inv = recip_x<X, T>(rho);
+    const X ux = (f_1 - f_3 + f_5 - f_6 - f_7 + f_8) * rho_inv;
+    const X uy = (f_2 - f_4 + f_5 + f_6 - f_7 - f_8) * rho_inv;
+    const X f45 = X(T(4.5)), f15 = X(T(1.5));
+    const X f49 = X(T(4. / 9.)), f19 = X(T(1. / 9.)), f136 = X(T(1. / 36.));
+    const X one = X(T(1)), three = X(T(3)), mthree = X(T(-3));
+    const X w_1_36 = rho * f136;
+    const X w_1_9 = rho * f19;
+    const X w_4_9 = rho * f49;
+    const X uxpuy = ux + uy;
+    const X uymux = uy - ux;
+    const X p_s = f45 * uxpuy, p_d = f45 * uymux, p_x = f45 * ux, p_y = f45 * uy;
+    const X usq = f15 * __builtin_elementwise_fma(ux, ux, uy * uy);
+    auto relax = [&](const X f, const X w, const X sign3, const X a, const X p) -> X {
+        const X bracket = __builtin_elementwise_fma(p, a, __builtin_elementwise_fma(sign3, a, one)) - usq;
+        return __builtin_elementwise_fma(om, __builtin_elementwise_fma(w, bracket, -f), f);
+    };
+    o[7] = relax(f_7, w_1_36, mthree, uxpuy, p_s);
+    o[4] = relax(f_4, w_1_9, mthree, uy, p_y);
+    o[8] = relax(f_8, w_1_36, mthree, uymux, p_d);
+    o[3] = relax(f_3, w_1_9, mthree, ux, p_x);
+    o[0] = __builtin_elementwise_fma(om, __builtin_elementwise_fma(w_4_9, one - usq, -f_0), f_0);
+    o[1] = relax(f_1, w_1_9, three, ux, p_x);
+    o[6] = relax(f_6, w_1_36, three, uymux, p_d);
+    o[2] = relax(f_2, w_1_9, three, uy, p_y);
+    o[5] = relax(f_5, w_1_36, three, uxpuy, p_s);
+}
+
+template <typename X, typename T, int ARITH>
+__device__ __forceinline__ void collide_arith(const X f_0, const X f_1, const X f_2, const X f_3,
+                                              const X f_4, const X f_5, const X f_6, const X f_7,
+                                              const X f_8, const T om, X (&o)[9])
+{
+    static_assert(ARITH >= kArithUnrolled && ARITH <= kArithContracted, "unknown arithmetic");
+    if constexpr (ARITH == kArithRolled)          collide_for_x<X, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    else if constexpr (ARITH == kArithContracted) collide_fma_x<X, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    else                                          collide_x<X, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+}
+
+template <typename T, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void collide(const T f_0, const T f_1, const T f_2, const T f_3,
                                         const T f_4, const T f_5, const T f_6, const T f_7,
                                         const T f_8, const T om, T (&o)[9])
 {
-    if constexpr (ROLLED) collide_for_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
-    else                  collide_x<T, T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    collide_arith<T, T, ARITH>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
 }
 
 // Relax the V nodes of one lane: c[q][i] -> o[q][i].  fp32 nodes go through the arithmetic in
 // pairs (packed instructions), everything else one by one.
-template <typename T, int V, bool PAIRS = true, bool ROLLED = false>
+template <typename T, int V, bool PAIRS = true, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], const T om)
 {
     if constexpr (PAIRS && sizeof(T) == 4 && V % 2 == 0) {
@@ -223,8 +309,7 @@ __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], 
             pair_t in[9], r[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) { in[q].x = c[q][i]; in[q].y = c[q][i + 1]; }
-            if constexpr (ROLLED) collide_for_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
-            else                  collide_x<pair_t, T>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
+            collide_arith<pair_t, T, ARITH>(in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], om, r);
 #pragma unroll
             for (int q = 0; q < 9; ++q) { o[q][i] = r[q].x; o[q][i + 1] = r[q].y; }
         }
@@ -232,7 +317,7 @@ __device__ __forceinline__ void collide_nodes(T (&o)[9][V], const T (&c)[9][V], 
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             T r[9];
-            collide<T, ROLLED>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
+            collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
 #pragma unroll
             for (int q = 0; q < 9; ++q) o[q][i] = r[q];
         }
@@ -465,7 +550,7 @@ k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 // ------------------------------------------------------------------------------------------
 // Single-node forms (any nx, explicit neighbour indices).  Used by the scalar kernels, by the
 // halo'd inner/outer forms and by the wall lanes of the lid kernels.
-template <typename T, bool ROLLED = false>
+template <typename T, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void pull_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
                                           uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
                                           uint32_t xr, uint32_t yd, uint32_t yu, T om)
@@ -480,12 +565,12 @@ __device__ __forceinline__ void pull_node(const T *__restrict__ f, T *__restrict
     const T f_2 = rowp(f, plane, 2, yd, nx)[x];
     const T f_5 = rowp(f, plane, 5, yd, nx)[xl];
     T o[9];
-    collide<T, ROLLED>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    collide<T, ARITH>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
 #pragma unroll
     for (int q = 0; q < 9; ++q) rowp(buf, plane, q, y, nx)[x] = o[q];
 }
 
-template <typename T, bool ROLLED = false>
+template <typename T, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict__ buf, size_t plane,
                                           uint32_t nx, uint32_t x, uint32_t y, uint32_t xl,
                                           uint32_t xr, uint32_t yd, uint32_t yu, T om)
@@ -494,7 +579,7 @@ __device__ __forceinline__ void push_node(const T *__restrict__ f, T *__restrict
 #pragma unroll
     for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
     T o[9];
-    collide<T, ROLLED>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
+    collide<T, ARITH>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
     rowp(buf, plane, 7, yd, nx)[xl] = o[7];
     rowp(buf, plane, 4, yd, nx)[x] = o[4];
     rowp(buf, plane, 8, yd, nx)[xr] = o[8];
@@ -533,7 +618,7 @@ __device__ __forceinline__ void lid_push_scatter(T *__restrict__ buf, size_t pla
 }
 
 // One node of push_lid_driven: pull-push.cpp:436-528.
-template <typename T>
+template <typename T, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void lid_push_node(const T *__restrict__ f, T *__restrict__ buf,
                                               size_t plane, uint32_t nx, uint32_t x, uint32_t y,
                                               bool l, bool r, bool t, bool b, T om, T df_lid)
@@ -542,14 +627,14 @@ __device__ __forceinline__ void lid_push_node(const T *__restrict__ f, T *__rest
 #pragma unroll
     for (int q = 0; q < 9; ++q) c[q] = rowp(f, plane, q, y, nx)[x];
     T o[9];
-    collide<T>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
+    collide<T, ARITH>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], om, o);
     lid_push_scatter<T>(buf, plane, nx, x, y, l, r, t, b, o, df_lid, 0u, nx - 1);
 }
 
 // One node of the lid-driven cavity in pull form: the store map of pull-push.cpp:520-528 read from
 // the destination side (no reference counterpart).  A population whose upstream node lies behind
 // a wall is the node's own opposite population; the two that bounce off the lid carry -+df.
-template <typename T>
+template <typename T, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void lid_pull_node(const T *__restrict__ f, T *__restrict__ buf,
                                               size_t plane, uint32_t nx, uint32_t x, uint32_t y,
                                               bool l, bool r, bool t, bool b, T om, T df_lid)
@@ -565,7 +650,7 @@ __device__ __forceinline__ void lid_pull_node(const T *__restrict__ f, T *__rest
     const T f_7 = (r || t) ? (rowp(f, plane, 5, y, nx)[x] - df) : rowp(f, plane, 7, y + 1, nx)[x + 1];
     const T f_8 = (l || t) ? (rowp(f, plane, 6, y, nx)[x] + df) : rowp(f, plane, 8, y + 1, nx)[x - 1];
     T o[9];
-    collide<T>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
+    collide<T, ARITH>(f_0, f_1, f_2, f_3, f_4, f_5, f_6, f_7, f_8, om, o);
 #pragma unroll
     for (int q = 0; q < 9; ++q) rowp(buf, plane, q, y, nx)[x] = o[q];
 }
@@ -835,8 +920,9 @@ k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, cons
 // ------------------------------------------------------------------------------------------
 // Scalar kernels: one node per lane over the rectangle [x_lo,x_hi) x [y_lo,y_hi).  Any nx.
 
-// ROLLED (periodic modes only): the reference's UNROLL_LOOPS=false arithmetic (collide_for_x).
-template <typename T, int MODE, int BLOCK, bool ROLLED = false>
+// ARITH: spelling of the relaxation (kArithRolled for the periodic modes only; the lid modes have
+// the unrolled spelling and its contraction).
+template <typename T, int MODE, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint32_t x_lo,
                uint32_t x_hi, int wrap_x, const T om, const T df_lid)
@@ -852,14 +938,15 @@ k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint3
             const uint32_t xr = wrap_x ? ((x + 1 == g.nx) ? 0u : x + 1) : x + 1;
             const uint32_t xl = wrap_x ? ((x == 0) ? g.nx - 1 : x - 1) : x - 1;
             const uint32_t yu = row_up(g, y), yd = row_down(g, y);
-            if (MODE == kPullPeriodic) pull_node<T, ROLLED>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
-            else                       push_node<T, ROLLED>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            if (MODE == kPullPeriodic) pull_node<T, ARITH>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+            else                       push_node<T, ARITH>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
         } else {
             const uint64_t yg = (uint64_t)((int64_t)y + g.y_goff);
             const bool t = (yg == g.ny_glob - 1), b = (yg == 0);
             const bool l = (x == 0), r = (x == g.nx - 1);
-            if (MODE == kPullLid) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
-            else                  lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+            constexpr int A = ARITH == kArithRolled ? kArithUnrolled : ARITH;
+            if (MODE == kPullLid) lid_pull_node<T, A>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+            else                  lid_push_node<T, A>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
         }
     }
 }
@@ -867,7 +954,7 @@ k_sweep_scalar(const T *__restrict__ f, T *__restrict__ buf, const Geom g, uint3
 // Ring of a halo'd array: pull_periodic_outer / push_periodic_outer (pull-push.cpp:335-429).
 // Lane i < nx-2 handles x=i+1 at y=1 and y=ny-2; lane nx-2+j, j < ny-4, handles y=j+2 at x=1 and
 // x=nx-2.
-template <typename T, bool PULL, int BLOCK, bool ROLLED = false>
+template <typename T, bool PULL, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t ny, const T om)
 {
@@ -883,13 +970,13 @@ k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t
         return;
     }
     if (PULL) {
-        pull_node<T, ROLLED>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        pull_node<T, ARITH>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
         if (xb != xa || yb != ya)
-            pull_node<T, ROLLED>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+            pull_node<T, ARITH>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
     } else {
-        push_node<T, ROLLED>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
+        push_node<T, ARITH>(f, buf, plane, nx, xa, ya, xa - 1, xa + 1, ya - 1, ya + 1, om);
         if (xb != xa || yb != ya)
-            push_node<T, ROLLED>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
+            push_node<T, ARITH>(f, buf, plane, nx, xb, yb, xb - 1, xb + 1, yb - 1, yb + 1, om);
     }
 }
 
@@ -1047,6 +1134,15 @@ __global__ void k_max_speed_finish(const uint32_t *__restrict__ key, T *__restri
 {
     const uint32_t k = *key;
     *out = (k == 0) ? (T)-1e30 : (T)__uint_as_float(k - 1u);
+}
+
+// out[i] = the contracted arithmetic's reciprocal of x[i] (recip_x), for the library's self-check.
+template <typename T>
+__global__ void __launch_bounds__(256) k_reciprocal(const T *__restrict__ x, T *__restrict__ out, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = recip_x<T, T>(x[i]);
 }
 
 }  // namespace lbm

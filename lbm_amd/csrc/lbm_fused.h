@@ -74,6 +74,7 @@ constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32
 #define LBM_FUSED_HALO_BYTES 32
 #endif
 constexpr int kFusedHaloBytes = LBM_FUSED_HALO_BYTES;  // granule of the x halo on either side of a strip: stored lanes then cover whole 64-byte lines
+constexpr int kFusedMaxStepsContracted = 8;   // with the contracted arithmetic (a third fewer vector instructions)
 constexpr int kFusedMaxSteps = 6;    // more steps gain nothing (16384^2 fp32 pull K=6/7/8: 280/284/274 GLUPS, push
                                      // 279/265/236; fp64 pull 138/141/135, push 132/129/117)
 // halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules
@@ -214,10 +215,10 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
 // fp32 nodes are relaxed in explicit packed pairs (collide_nodes): 7 % faster than leaving the pairing
 // to the compiler in the periodic sweeps (240 -> 256 GLUPS at 16384^2, four steps), 4-10 % in the
 // lid-driven ones.
-template <typename T, int V, bool ROLLED = false>
+template <typename T, int V, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void relax_row(T (&o)[9][V], const T (&c)[9][V], const T om)
 {
-    collide_nodes<T, V, true, ROLLED>(o, c, om);
+    collide_nodes<T, V, true, ARITH>(o, c, om);
 }
 
 // Array-of-structures lattices ([NY][NX][9], the reference's VIEW(view, x, y, q) = view(y, x, q) of
@@ -263,8 +264,9 @@ struct RowIn {
 // K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
 // AOS: the arrays are [NY][NX][9].  The pull scheme then reads each row's own nine (post-collision)
 // populations like the push scheme does and streams every step in registers, the first one included.
-// ROLLED: the reference's UNROLL_LOOPS=false arithmetic (collide_for_x); periodic scenes only, as there.
-template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, bool ROLLED = false>
+// ARITH: spelling of the relaxation (lbm_device.h).  kArithRolled is the reference's UNROLL_LOOPS=false
+// arithmetic (periodic scenes only, as there); kArithContracted the explicit fused multiply-adds.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
@@ -450,7 +452,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         };
         T o[9][V];
         if (PUSH) {
-            relax_row<T, V, ROLLED>(o, in.v, om);
+            relax_row<T, V, ARITH>(o, in.v, om);
         } else if (AOS) {
 #pragma unroll
             for (int q = 0; q < 9; ++q)
@@ -489,7 +491,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                 own8_right = in.v[8][V - 1];
             }
             gather_row<T, V, LID, false, WALLS>(c, A, B, F, F, w7, w6, w8, w5, fl, df_lid);
-            relax_row<T, V, ROLLED>(o, c, om);
+            relax_row<T, V, ARITH>(o, c, om);
         }
 #pragma unroll
         for (int s = 0; s < NG; ++s) {
@@ -551,7 +553,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 #pragma unroll
                     for (int e = 0; e < V; ++e) o[q][e] = c[q][e];
             } else {
-                relax_row<T, V, ROLLED>(o, c, om);
+                relax_row<T, V, ARITH>(o, c, om);
             }
         }
         if (i >= (uint32_t)(D + NG) && store_lane) {
@@ -609,12 +611,13 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
 // scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
 // every instantiation fits without spilling (at most 239 VGPRs).
-template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, bool ROLLED = false>
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
-    static_assert(!ROLLED || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
-    fused_body<T, V, K, PUSH, LID, AOS, ROLLED>(f, buf, g, om, df_lid);
+    static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
+    static_assert(ARITH != kArithContracted || !AOS, "the contracted arithmetic is built for [9][NY][NX] arrays only");
+    fused_body<T, V, K, PUSH, LID, AOS, ARITH>(f, buf, g, om, df_lid);
 }
 
 }  // namespace lbm

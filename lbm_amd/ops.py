@@ -62,6 +62,32 @@ def get_unroll_loops() -> bool:
     return bool(capi.load().lbm_get_unroll_loops())
 
 
+ARITHMETICS = {"unrolled": 0, "rolled": 1, "contracted": 2}
+
+
+def set_arithmetic(name: str) -> None:
+    """Process-wide spelling of the relaxation: "unrolled" (pull-push.cpp:25-72 as written, default),
+    "rolled" (the reference's UNROLL_LOOPS=false functions) or "contracted" (explicit fused
+    multiply-adds where the reference's own build flags allow a compiler to fuse)."""
+    capi.call("lbm_set_arithmetic", ARITHMETICS[name])
+
+
+def get_arithmetic() -> str:
+    v = int(capi.load().lbm_get_arithmetic())
+    return [k for k, x in ARITHMETICS.items() if x == v][0]
+
+
+@contextlib.contextmanager
+def arithmetic(name: str):
+    """`with ops.arithmetic("contracted"): ...` -- switch the process-wide arithmetic for a block."""
+    before = get_arithmetic()
+    set_arithmetic(name)
+    try:
+        yield
+    finally:
+        set_arithmetic(before)
+
+
 @contextlib.contextmanager
 def unroll_loops(unrolled: bool):
     """`with ops.unroll_loops(False): ...` -- switch the process-wide arithmetic for a block."""
@@ -291,3 +317,13 @@ def max_velocity(f, LY=0, HY=None) -> float:
     out = C.c_double(0.0)
     _run("lbm_max_velocity", f, f.data_ptr(), _prec(f), nx, ny, int(LY), HY, _stream(f), C.byref(out))
     return out.value
+
+
+def selftest_reciprocal(x: torch.Tensor) -> torch.Tensor:
+    """1/x element-wise as the "contracted" arithmetic forms the reciprocal of the density
+    (pull-push.cpp:27); the tests hold it to the correctly rounded quotient."""
+    if not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be a contiguous device tensor")
+    out = torch.empty_like(x)
+    _run("lbm_selftest_reciprocal", x, x.data_ptr(), out.data_ptr(), _prec(x), x.numel(), _stream(x))
+    return out

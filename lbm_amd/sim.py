@@ -59,6 +59,7 @@ class Simulation:
         self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
         self.t = 0
         self.launches = 0   # sweep launches so far (a launch advances 1..6 steps)
+        self.launch_steps = []   # steps taken by each of the most recent launches (bounded)
         self._vel: Optional[torch.Tensor] = None
         self._mag: Optional[torch.Tensor] = None
         if scene == LID_DRIVEN:
@@ -94,6 +95,8 @@ class Simulation:
             self.f, self.buf = self.buf, self.f
             self.t += k
             self.launches += 1
+            self.launch_steps.append(k)
+            del self.launch_steps[:-4096]
             n -= k
 
     def max_velocity(self) -> float:

@@ -179,6 +179,7 @@ class SlabSimulation:
         self.f[:, :G].zero_(); self.f[:, n + G:].zero_()
         self.buf[:, :G].zero_(); self.buf[:, n + G:].zero_()
         self.blocks = 0     # exchanges so far = launches of the interior sweep
+        self.launch_steps = []   # steps taken by each of the most recent blocks (bounded)
         self._stage = None  # deep-halo staging buffers, allocated at the first exchange
         self._max = torch.empty(2, dtype=dtype, device=self.device)
         self.t = 0
@@ -212,11 +213,13 @@ class SlabSimulation:
             backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob, halo=G)
         else:
             backend.init_shearwave(self.f, self.rho, self.u, self.y_below, self.ny_glob)
+        if self.overlap:
+            # the edge stream's first sweeps and exchanges come after the initialisation, whatever
+            # the schedule (the initialisers run on the compute stream)
+            self._interior_done[1].record(self.compute_stream)
+            self.comm_stream.wait_event(self._interior_done[1])
         if self.deep or self.scheme == "pull":
             # pull reads ghost rows of f: fill them from the neighbours' initial edge rows
-            if self.overlap:
-                self._interior_done[1].record(self.compute_stream)   # initialisation finished
-                self.comm_stream.wait_event(self._interior_done[1])
             if self.deep:
                 self._exchange_deep(self.f)
             else:
@@ -386,6 +389,8 @@ class SlabSimulation:
             self._sweep_fused(2 * G, n, k)
         self.f, self.buf = self.buf, self.f
         self.blocks += 1
+        self.launch_steps.append(k)
+        del self.launch_steps[:-4096]
         self.t += k
 
     def _peer(self, group_rank: int) -> int:
@@ -414,9 +419,12 @@ class SlabSimulation:
         n = self.n
         pull = self.scheme == "pull"
         if self.deep:
+            # the fewest blocks of at most G steps, as equal as possible (a short tail block pays a
+            # whole pass over memory and a whole exchange for its few steps)
             nsteps = int(nsteps)
             while nsteps > 0:
-                k = min(self.G, nsteps)
+                blocks = -(-nsteps // self.G)
+                k = -(-nsteps // blocks)
                 self._block(k)
                 nsteps -= k
             return
@@ -450,6 +458,8 @@ class SlabSimulation:
             self.f, self.buf = self.buf, self.f
             self.t += 1
             self.blocks += 1
+            self.launch_steps.append(1)
+            del self.launch_steps[:-4096]
 
     # ------------------------------------------------------------------ observables ----------
     def max_velocity(self) -> float:

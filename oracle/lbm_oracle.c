@@ -20,22 +20,30 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-/* 0: pull_periodic / push_periodic (UNROLL_LOOPS true, the default); 1: the *_for spelling. */
-static int orc_rolled = 0;
-void orc_set_rolled(int rolled) { orc_rolled = rolled; }
-int orc_get_rolled(void) { return orc_rolled; }
+/* Spelling of the relaxation: 0 = pull_periodic / push_periodic (UNROLL_LOOPS true, the default);
+ * 1 = the *_for spelling (periodic sweeps only); 2 = collide_fma, one explicit fused-multiply-add
+ * contraction of spelling 0 (all sweeps). */
+static int orc_arith = 0;
+void orc_set_arithmetic(int arith) { orc_arith = (arith == 1 || arith == 2) ? arith : 0; }
+int orc_get_arithmetic(void) { return orc_arith; }
+void orc_set_rolled(int rolled) { orc_arith = rolled ? 1 : 0; }
+int orc_get_rolled(void) { return orc_arith == 1; }
 
 #define FLT float
 #define SUFFIX _f32
+#define ORC_FMA fmaf
 #include "lbm_oracle_impl.h"
 #undef FLT
 #undef SUFFIX
+#undef ORC_FMA
 
 #define FLT double
 #define SUFFIX _f64
+#define ORC_FMA fma
 #include "lbm_oracle_impl.h"
 #undef FLT
 #undef SUFFIX
+#undef ORC_FMA
 
 /* Library self-description, so a loader can check what it got. */
 const char *orc_build_info(void)

@@ -86,11 +86,64 @@ static inline void FN(collide_for)(const FLT f[9], FLT out[9], const FLT OMEGA)
     }
 }
 
+/* One contraction of FN(collide) that a compiler is free to apply to the reference's text: the
+ * reference is built -O3 -march=native (CMakeLists.txt:18; nvcc and hipcc contract by default too),
+ * where every a*b+c of pull-push.cpp:25-72 may become one fused multiply-add.  Which ones do is the
+ * compiler's choice and differs from build to build; this function fixes one choice, spelled with
+ * explicit fma calls so that it does not depend on the flags of THIS build:
+ *     ux*ux + uy*uy          -> fma(ux, ux, uy*uy)
+ *     1 -+ 3*a               -> fma(-+3, a, 1)
+ *     ... + (f45*a)*a        -> fma(f45*a, a, ...)
+ *     (w*bracket) - f        -> fma(w, bracket, -f)
+ *     f + OMEGA*(...)        -> fma(OMEGA, ..., f)
+ * Sums, the division and every other product round as in FN(collide).  It is the checker of the
+ * HIP library's LBM_ARITH_CONTRACTED mode, and is itself held to FN(collide) within the parity
+ * budget (1e-5 fp32 / 1e-12 fp64 on populations) and to the recorded decay series by the tests. */
+static inline void FN(collide_fma)(const FLT in[9], FLT out[9], const FLT OMEGA)
+{
+    const FLT f_0 = in[0], f_1 = in[1], f_2 = in[2], f_3 = in[3], f_4 = in[4];
+    const FLT f_5 = in[5], f_6 = in[6], f_7 = in[7], f_8 = in[8];
+    const FLT rho = f_0 + f_1 + f_2 + f_3 + f_4 + f_5 + f_6 + f_7 + f_8;
+    const FLT one = (FLT)1.0, three = (FLT)3.0;
+    const FLT rho_inv = one / rho;
+    const FLT ux = (f_1 - f_3 + f_5 - f_6 - f_7 + f_8) * rho_inv;
+    const FLT uy = (f_2 - f_4 + f_5 + f_6 - f_7 - f_8) * rho_inv;
+    const FLT f45 = (FLT)4.5, f15 = (FLT)1.5;
+    const FLT f49 = (FLT)(4. / 9.), f19 = (FLT)(1. / 9.), f136 = (FLT)(1. / 36.);
+    const FLT w_1_36 = rho * f136;
+    const FLT w_1_9 = rho * f19;
+    const FLT w_4_9 = rho * f49;
+    const FLT uxpuy = ux + uy;
+    const FLT uymux = uy - ux;
+    const FLT p_s = f45 * uxpuy, p_d = f45 * uymux, p_x = f45 * ux, p_y = f45 * uy;
+    const FLT usq = f15 * ORC_FMA(ux, ux, uy * uy);
+#define ORC_RELAX(f, w, sign3, a, p) \
+    ORC_FMA(OMEGA, ORC_FMA((w), ORC_FMA((p), (a), ORC_FMA((sign3), (a), one)) - usq, -(f)), (f))
+    out[7] = ORC_RELAX(f_7, w_1_36, -three, uxpuy, p_s);
+    out[4] = ORC_RELAX(f_4, w_1_9, -three, uy, p_y);
+    out[8] = ORC_RELAX(f_8, w_1_36, -three, uymux, p_d);
+    out[3] = ORC_RELAX(f_3, w_1_9, -three, ux, p_x);
+    out[0] = ORC_FMA(OMEGA, ORC_FMA(w_4_9, one - usq, -f_0), f_0);
+    out[1] = ORC_RELAX(f_1, w_1_9, three, ux, p_x);
+    out[6] = ORC_RELAX(f_6, w_1_36, three, uymux, p_d);
+    out[2] = ORC_RELAX(f_2, w_1_9, three, uy, p_y);
+    out[5] = ORC_RELAX(f_5, w_1_36, three, uxpuy, p_s);
+#undef ORC_RELAX
+}
+
 /* What the periodic sweeps call: pull-push.cpp:259-263, :281-285 and the six further
- * `#if UNROLL_LOOPS` sites of the inner / outer forms.  The lid-driven sweep has one spelling. */
+ * `#if UNROLL_LOOPS` sites of the inner / outer forms. */
 static inline void FN(collide_sel)(const FLT in[9], FLT out[9], const FLT OMEGA)
 {
-    if (orc_rolled) FN(collide_for)(in, out, OMEGA);
+    if (orc_arith == 1) FN(collide_for)(in, out, OMEGA);
+    else if (orc_arith == 2) FN(collide_fma)(in, out, OMEGA);
+    else FN(collide)(in, out, OMEGA);
+}
+/* The lid-driven sweep has one spelling in the reference (pull-push.cpp:454-483), and its
+ * contraction. */
+static inline void FN(collide_lid_sel)(const FLT in[9], FLT out[9], const FLT OMEGA)
+{
+    if (orc_arith == 2) FN(collide_fma)(in, out, OMEGA);
     else FN(collide)(in, out, OMEGA);
 }
 
@@ -336,7 +389,7 @@ void FN(orc_push_lid_rows)(const FLT *f, FLT *buf, uint64_t nx, uint64_t ny, uin
         for (uint64_t x = 0; x < nx; ++x) {
             FLT in[9], o[9];
             for (unsigned q = 0; q < 9; ++q) in[q] = AT(f, q, y, x);
-            FN(collide)(in, o, OMEGA);
+            FN(collide_lid_sel)(in, o, OMEGA);
             const int l = (x == 0), r = (x == nx - 1);          /* :496-499 */
             const int t = (yg == ny_glob - 1), b = (yg == 0);
             const int lb = l || b, lt = l || t, rb = r || b, rt = r || t; /* :500-503 */
@@ -387,7 +440,7 @@ void FN(orc_pull_lid_rows)(const FLT *f, FLT *buf, uint64_t nx, uint64_t ny, uin
             in[6] = (r || b) ? AT(f, 8, y, x) : AT(f, 6, y - 1, x + 1);
             in[7] = (r || t) ? (AT(f, 5, y, x) - df) : AT(f, 7, y + 1, x + 1);
             in[8] = (l || t) ? (AT(f, 6, y, x) + df) : AT(f, 8, y + 1, x - 1);
-            FN(collide)(in, o, OMEGA);
+            FN(collide_lid_sel)(in, o, OMEGA);
             for (unsigned q = 0; q < 9; ++q) AT(buf, q, y, x) = o[q];
         }
     }

@@ -96,6 +96,38 @@ def get_rolled() -> bool:
     return bool(lib().orc_get_rolled())
 
 
+ARITHMETICS = {"unrolled": 0, "rolled": 1, "contracted": 2}
+
+
+def set_arithmetic(name: str) -> None:
+    """Spelling of the relaxation: "unrolled" (pull-push.cpp:25-72, the default), "rolled" (the
+    *_for functions, periodic sweeps only) or "contracted" (collide_fma: one explicit
+    fused-multiply-add contraction of the unrolled spelling, the checker of the HIP library's
+    LBM_ARITH_CONTRACTED mode)."""
+    lib().orc_set_arithmetic(ARITHMETICS[name])
+
+
+def get_arithmetic() -> str:
+    v = int(lib().orc_get_arithmetic())
+    return [k for k, x in ARITHMETICS.items() if x == v][0]
+
+
+class arithmetic:
+    """``with orc.arithmetic("contracted"): ...``"""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = get_arithmetic()
+        set_arithmetic(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_arithmetic(self.prev)
+        return False
+
+
 def num_threads() -> int:
     """OpenMP threads the oracle's row loops use."""
     fn = lib().orc_num_threads

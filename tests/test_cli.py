@@ -158,7 +158,9 @@ def test_unroll_loops_false_build_follows_the_rolled_spelling():
 @pytest.mark.gpu
 def test_double_precision_build(golden_dir):
     """build/main_f64 is the driver compiled with USE_SINGLE_PRECISION=false (reference macros.h:5,
-    global.h:21-27): the whole config-1 series as the reference's own sources print it in fp64."""
+    global.h:21-27): the whole config-1 series in fp64 as the survey of the reference recorded it from
+    the reference's sources compiled against a stand-in Kokkos header (a consistency check, not a
+    pin: the reference's own build was never run)."""
     import json
     with open(os.path.join(golden_dir, "config1_series.json")) as fh:
         gold = json.load(fh)

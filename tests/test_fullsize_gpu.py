@@ -55,6 +55,25 @@ def test_shear_wave_32768x4096_fp32_pull_equals_narrow_oracle():
     _free()
 
 
+def test_config5_shear_wave_32768sq_fp32_pull_equals_narrow_oracle():
+    """BASELINE config 5 at its own size on one device (2 x 38.65 GB resident): 12 steps, every one
+    of the 32768 columns bit-equal to the oracle's 8-column run, max |u| and mass included."""
+    from lbm_amd import Simulation
+    nx = ny = 32768
+    steps, omega = 12, 0.5
+    sim = Simulation(nx, ny, scene="shear", scheme="pull", dtype=torch.float32, omega=omega)
+    sim.step(steps)
+    want, _ = orc.run("shear", "pull", 8, ny, steps, omega, np.float32)
+    col = torch.from_numpy(np.ascontiguousarray(want[:, :, :1])).cuda()
+    for q in range(9):      # plane by plane: the comparison's temporaries stay at 1 GB
+        assert bool((sim.f[q].view(torch.int32) == col[q].view(torch.int32)).all()), q
+    assert sim.max_velocity() == float(orc.max_velocity(want))
+    total = sum(float(sim.f[q].sum(dtype=torch.float64)) for q in range(9))
+    assert abs(total - nx * ny) / (nx * ny) < 1e-6
+    del sim
+    _free()
+
+
 @pytest.mark.parametrize("scheme", ["push", "pull"])
 def test_lid_cavity_16384sq_fp64_corners_and_bands_equal_small_cavity(scheme):
     from lbm_amd import Simulation

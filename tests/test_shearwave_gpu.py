@@ -70,9 +70,10 @@ def test_viscosity_push_matches_pull():
 
 @pytest.mark.parametrize("prec", ["fp32", "fp64"])
 def test_baseline_config1_series(golden_dir, prec):
-    """`-nx 1024 -ny 1024 -w 0.5 -s 50000 -of 500 -omv` (pull): the 100 values the reference's own
-    sources print for this command (tests/golden/config1_series.json), and the viscosity fitted
-    from them as shear-wave.py:78-80 fits it (analytic 0.5)."""
+    """`-nx 1024 -ny 1024 -w 0.5 -s 50000 -of 500 -omv` (pull): the 100 values recorded in the survey
+    of the reference from its sources compiled against a stand-in Kokkos header
+    (tests/golden/config1_series.json; a consistency check, not a pin -- the reference's own build was
+    never run), and the viscosity fitted from them as shear-wave.py:78-80 fits it (analytic 0.5)."""
     import torch
     from lbm_amd import Simulation
     with open(os.path.join(golden_dir, "config1_series.json")) as fh:
