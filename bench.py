@@ -5,11 +5,11 @@
                     [--scene shear|lid] [--nx NX] [--ny-per-gpu NY]
 
 One "step" is one time step: every node of the lattice relaxed and streamed once.  The time loop
-hands runs of up to six steps to one fused launch (same populations bit for bit, one
+hands runs of up to eight steps to one fused launch (same populations bit for bit, one
 pass over HBM instead of six); --max-fuse 1 times the one-step sweep instead.  N=1 runs the single-GPU
 configuration (shear-wave decay, 16384 x 16384, fp32, pull streaming).  N>1 (launched by
 torch.distributed.run, one rank per GPU) gives every rank a 16384 x 16384 y-slab of a
-16384 x (16384*N) lattice and refreshes six ghost rows per slab edge once per six steps over
+16384 x (16384*N) lattice and refreshes up to eight ghost rows per slab edge once per as many steps over
 RCCL, overlapped with the interior update: weak scaling, value = all ranks' lattice updates per
 second.
 
@@ -83,7 +83,7 @@ def parse():
                     help="N=1 only: run the y-slab code path with this GPU as its own periodic neighbour "
                          "(halo rows through RCCL send/recv to self) to price the decomposition overhead")
     ap.add_argument("--max-fuse", type=int, default=0,
-                    help="upper bound on time steps per launch (0 = library default of 6, 1 = one-step sweeps)")
+                    help="upper bound on time steps per launch (0 = library default of 7 or 8, 1 = one-step sweeps)")
     ap.add_argument("--threads-x", type=int, default=0, help="workgroup width hint (0 = built-in)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="resident-wave cap hint (0 = built-in)")
     return ap.parse_args()

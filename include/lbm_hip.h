@@ -82,8 +82,7 @@ int lbm_get_unroll_loops(void);
  *                         nvcc and hipcc contract by default): ux*ux+uy*uy, 1 -+ 3a, + (4.5a)a,
  *                         w*(...) - f and f + om*(...) each become one fused multiply-add; sums, the
  *                         reciprocal of the density (correctly rounded) and all other products are
- *                         unchanged.  A third fewer vector instructions per node, and up to eight
- *                         time steps per *_fused call.  Populations stay within the parity budget of
+ *                         unchanged.  A third fewer vector instructions per node.  Populations stay within the parity budget of
  *                         the unrolled spelling (fp32 1e-5, fp64 1e-12 max-abs over thousands of
  *                         steps; measured 2e-7 / 1e-15).  All sweeps on [9][NY][NX] arrays; the
  *                         one-step entry points run element-wise kernels.  fp32 rows must have an even
@@ -180,14 +179,14 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * Returns LBM_ERR_UNSUPPORTED (nothing launched) for rows of a single node; callers then take
  * nsteps one-step sweeps. */
 
-/* Largest nsteps the fused entry points accept for this precision and row length: 6 (8 with
- * LBM_ARITH_CONTRACTED), or 1 when the row length is unsupported. */
+/* Largest nsteps the fused entry points accept for this precision and row length: 8, or 1 when the
+ * row length is unsupported. */
 int lbm_fused_max_steps(int prec, uint64_t nx);
 
 /* How many of the `remaining` iterations of the time loop the next call should take for a lattice
  * of `rows` rows of nx nodes: the run is cut into the fewest launches of at most
  * lbm_fused_max_steps() steps (fewer on small lattices; 1 for row lengths the fused sweeps do not
- * support) and those launches are made as equal as possible (20 remaining -> 5, then 5, 5, 5).  Environment: LBM_FUSED_MAX_STEPS caps the answer,
+ * support) and those launches are made as equal as possible (20 remaining -> 7, then 7, 6).  Environment: LBM_FUSED_MAX_STEPS caps the answer,
  * LBM_FUSED_MIN_NODES makes lattices below that many nodes take one step per launch.  The time loops of this library's drivers (main.cpp:64-83) ask this before
  * every launch. */
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining);

@@ -23,6 +23,10 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",       # no a*b+c fusion: bit-parity with a strict evaluation of the reference
     "-fno-fast-math",
+    # instruction scheduling for latency rather than for the fewest registers: a dependent packed-fp32
+    # operation issues ~2.2 x later than an independent one, and the default strategy leaves a third
+    # of them back to back (16384^2 fp32, seven steps per launch: 380 -> 397 GLUPS)
+    "-mllvm", "-amdgpu-sched-strategy=max-ilp",
     "-fPIC",
     "-shared",
     "-Wall",

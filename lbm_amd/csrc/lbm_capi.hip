@@ -476,10 +476,7 @@ int fused_wall_split_default()
 }
 int g_fused_wall_split = fused_wall_split_default();
 
-int max_fused_steps(int /*prec*/)
-{
-    return g_arith == lbm::kArithContracted ? lbm::kFusedMaxStepsContracted : lbm::kFusedMaxSteps;
-}
+int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
 // Wavefronts the device holds at once at two per SIMD (the residency of every multi-step kernel):
 // compute units x 4 SIMDs x 2.  2048 on a whole MI355X; a partition (CPX, DPX) has fewer units.
@@ -511,8 +508,11 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
                  int wrap_y, int64_t y_goff, uint64_t ny_glob, int k, hipStream_t stream)
 {
     // lanes stored per strip: 56, or 48 for fp64 beyond four steps (wider x halo)
-    static_assert(lbm::fused_halo_lanes<T, V, 5>() == lbm::fused_halo_lanes<T, V, lbm::kFusedMaxStepsContracted>(),
+    static_assert(lbm::fused_halo_lanes<T, V, 5>() == lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>(),
                   "one halo width for every step count above four");
+    // rows are addressed through buffer descriptors with 32-bit byte offsets
+    if (nx * sizeof(T) >= (uint64_t)lbm::kNoStore)
+        return fail(LBM_ERR_UNSUPPORTED, "rows of %llu nodes are too long for the multi-step sweeps", (unsigned long long)nx);
     const uint64_t W = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>() : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
     const uint64_t rows = y_hi - y_lo;
     const uint64_t nstrips = (nx / V + W - 1) / W;
@@ -541,8 +541,11 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
             // Larger grids: the same count, over the lengths at which a wavefront is as efficient
             // as at 128 rows.  16384^2 in 128-row segments is 9.2 rounds, in 118-row ones 9.98:
             // fp32 pull 296 -> 305 GLUPS, push 294 -> 301, cavity push 300 -> 309.
+            // Seven and eight steps have more rows of y halo to amortise: 140 to 186 rows there
+            // (16384^2 fp32, eight steps, GLUPS at 100/118/140/160/186/223/279/372 rows:
+            // 406/418/420/423/424/423/417/404).
             uint64_t best = ~0ull;
-            for (uint64_t s = 128; s >= 96; --s) {
+            for (uint64_t s = (k >= 7 ? 186 : 128); s >= (k >= 7 ? 140u : 96u); --s) {
                 const uint64_t waves = nstrips * ((rows + s - 1) / s);
                 const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
                 if (cost < best) { best = cost; seg = s; }
@@ -587,15 +590,6 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     case KK:                                                                                                     \
         hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>), grid, block, 0, stream, f, buf, g, om, df); \
         break;
-    if constexpr (ARITH == lbm::kArithContracted) {
-        // fewer vector instructions per step: more steps per pass over memory pay
-        switch (k) {
-            LBM_FUSED_CASE(7)
-            LBM_FUSED_CASE(8)
-            default: break;
-        }
-        if (k == 7 || k == 8) return launch_status("fused sweep");
-    }
     switch (k) {
         LBM_FUSED_CASE(1)
         LBM_FUSED_CASE(2)
@@ -603,6 +597,8 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         LBM_FUSED_CASE(4)
         LBM_FUSED_CASE(5)
         LBM_FUSED_CASE(6)
+        LBM_FUSED_CASE(7)
+        LBM_FUSED_CASE(8)
         default: return fail(LBM_ERR_INVALID_ARGUMENT, "fused step count %d outside 1..%d", k, max_fused_steps(0));
     }
 #undef LBM_FUSED_CASE
@@ -1090,7 +1086,12 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     // the longer ramp of a wavefront (fp32 pull, GLUPS at 4 / 6 steps: 512^2 47 / 35, 1024^2 108 / 92,
     // 1536^2 150 / 145, 2048^2 174 / 180, 4096^2 232 / 261, 8192^2 252 / 290, 16384^2 250 / 285).
     // The smallest ones (fp32 pull, 3 / 4 steps: 256^2 17.1 / 16.7, 512^2 56 / 49, 1024^2 118 / 120) take three.
+    // Large lattices (16384^2, GLUPS at 6/7/8 steps): fp32 strict 325/334/335, contracted 377/410/424
+    // (push 372/401/411); fp64 contracted pull 162/167/171, push 159/166/162.  The strict and rolled
+    // spellings and the fp64 sweeps take seven (an eighth step gains little or nothing and deepens
+    // the halos of a decomposed run), contracted fp32 eight.
     uint64_t dflt = (uint64_t)kmax;
+    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
     if (dflt > 4 && nx * rows < (3ull << 20)) dflt = 4;
     if (dflt > 3 && nx * rows < 600000ull) dflt = 3;
     const char *m = getenv("LBM_FUSED_MAX_STEPS");

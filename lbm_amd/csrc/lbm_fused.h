@@ -2,7 +2,7 @@
 //
 // A single collide-and-stream step moves 18 populations per node through HBM for ~110 flops: the
 // one-step sweeps of lbm_device.h sit at the memory roofline with the vector ALUs 80 % idle.  These
-// kernels advance K = 1..6 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
+// kernels advance K = 1..8 steps of the reference's time loop (main.cpp:64-83: sweep, swap, sweep,
 // ...) while reading every population once and writing it once:
 //
 //   * one wavefront owns a strip of 64 x 8 bytes of a row and marches it through a segment of
@@ -51,12 +51,13 @@
 
 #pragma clang fp contract(off)
 
-// Streaming steps whose rings stay in registers (the rest live in LDS); tuning harnesses override.
+// Streaming steps whose rings stay in registers (the rest live in LDS); tuning harnesses override
+// (0 = the built-in choice, fused_reg_rings()).
 #ifndef LBM_FUSED_REG_RINGS_PULL
-#define LBM_FUSED_REG_RINGS_PULL 2
+#define LBM_FUSED_REG_RINGS_PULL 0
 #endif
 #ifndef LBM_FUSED_REG_RINGS_PUSH
-#define LBM_FUSED_REG_RINGS_PUSH 2
+#define LBM_FUSED_REG_RINGS_PUSH 0
 #endif
 // Rows requested ahead of their use (fp32 with two: no gain, 16384^2 six steps 318 vs 316 GLUPS on
 // constant data, and the cavity kernels reach 255 VGPRs).
@@ -74,13 +75,29 @@ constexpr int kFusedLaneBytes = 8;   // bytes of a row owned by one lane: 2 fp32
 #define LBM_FUSED_HALO_BYTES 32
 #endif
 constexpr int kFusedHaloBytes = LBM_FUSED_HALO_BYTES;  // granule of the x halo on either side of a strip: stored lanes then cover whole 64-byte lines
-constexpr int kFusedMaxStepsContracted = 8;   // with the contracted arithmetic (a third fewer vector instructions)
-constexpr int kFusedMaxSteps = 6;    // more steps gain nothing (16384^2 fp32 pull K=6/7/8: 280/284/274 GLUPS, push
-                                     // 279/265/236; fp64 pull 138/141/135, push 132/129/117)
+constexpr int kFusedMaxSteps = 8;    // 16384^2 fp32 pull, GLUPS at 5/6/7/8 steps per launch: strict arithmetic 308/325/334/335,
+                                     // contracted 326/377/410/424; fp64 contracted 154/162/167/171 (five steps and fewer run
+                                     // at the memory roof, each further step costs less than it saves until the rings of
+                                     // nine or more steps would cut the residency)
 // halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules
 template <typename T, int V, int K> constexpr int fused_halo_lanes()
 {
     return ((K * (int)sizeof(T) + kFusedHaloBytes - 1) / kFusedHaloBytes) * kFusedHaloBytes / (V * (int)sizeof(T));
+}
+
+// Rings kept in registers.  With row addresses in scalar registers (row_load / row_store) the
+// periodic fp32 kernels have room for four (16384^2, eight steps: 2 rings 388 GLUPS, 3 rings 410,
+// 4 rings 412; push 344 / 388 / 411).  Everything else keeps two: the fp64 kernels spill a few
+// registers with three (and run 2 % faster all the same) and badly with four (171 -> 81 GLUPS), the
+// rolled arithmetic spills with four, the cavity kernels carry the wall cases in registers as well.
+// No instantiation of the library uses scratch memory.
+template <typename T, int V, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_reg_rings()
+{
+    constexpr int forced = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
+    if (forced > 0) return forced;
+    if (LID || AOS || ARITH == kArithRolled || sizeof(T) == 8) return 2;
+    return 4;
 }
 
 struct FusedGeom {
@@ -136,6 +153,48 @@ __device__ __forceinline__ void arrive_from_right(T (&d)[V], const T (&s)[V])
     d[V - 1] = from_lane_above(s[0]);
 #pragma unroll
     for (int i = 0; i < V - 1; ++i) d[i] = s[i + 1];
+}
+
+// Row accesses of the [9][NY][NX] sweeps go through buffer descriptors: the 64-bit row base is
+// wave-uniform and lives in scalar registers, a lane adds a 32-bit byte offset, and the range check
+// of the descriptor drops the access of any lane whose offset lies at or beyond `bytes`.  The
+// stores use that instead of a branch around them: lanes of the x halo pass kNoStore as their
+// offset, iterations that store nothing pass bytes = 0.  (Stores under a divergent branch made the
+// compiler wait for vmcnt(0) where the branch rejoins -- for the stores themselves, every
+// iteration; and per-lane 64-bit addresses cost a vector add per access.)
+constexpr uint32_t kNoStore = 0x80000000u;   // beyond any row: rows are shorter than 2 GiB here
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T, int V>
+__device__ __forceinline__ void row_load(T (&r)[V], const T *row, uint32_t bytes, uint32_t voff)
+{
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(row), 0, (int)bytes, 0x00020000);
+    if constexpr (V * sizeof(T) == 8) {
+        union { u32x2 u; T t[V]; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b64(d, (int)voff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = c.t[i];
+    } else {
+        static_assert(V == 1 && sizeof(T) == 4, "8 or 4 bytes per lane");
+        union { unsigned u; T t; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b32(d, (int)voff, 0, 0);
+        r[0] = c.t;
+    }
+}
+// non-temporal like store_a: the write stream is never re-read within a sweep
+template <typename T, int V>
+__device__ __forceinline__ void row_store(T *row, uint32_t bytes, uint32_t voff, const T (&r)[V])
+{
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int)bytes, 0x00020000);
+    if constexpr (V * sizeof(T) == 8) {
+        union { u32x2 u; T t[V]; } c;
+#pragma unroll
+        for (int i = 0; i < V; ++i) c.t[i] = r[i];
+        __builtin_amdgcn_raw_buffer_store_b64(c.u, d, (int)voff, 0, 2);
+    } else {
+        union { unsigned u; T t; } c;
+        c.t = r[0];
+        __builtin_amdgcn_raw_buffer_store_b32(c.u, d, (int)voff, 0, 2);
+    }
 }
 
 // What a lane knows about walls (lid scenes only; all false otherwise).
@@ -323,6 +382,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     const uint32_t x0 = (uint32_t)vx * V;
     const uint32_t wcount = min((uint32_t)W, nxv - strip * W);
     const bool store_lane = lane >= (uint32_t)H && lane < H + wcount;
+    const uint32_t row_bytes = g.nx * (uint32_t)sizeof(T);
+    const uint32_t xoff = x0 * (uint32_t)sizeof(T);                // a lane's byte offset in any row
+    const uint32_t xoff_store = store_lane ? xoff : kNoStore;
     WallFlags fl0;
     fl0.t = false; fl0.b = false;
     fl0.l = LID && x0 == 0;
@@ -371,20 +433,20 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
             load_aos<T, V>(d.v, f + ((size_t)y * g.nx + x0) * 9);
         } else if (PUSH) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) load_a<T, V>(d.v[q], rowp(f, plane, q, y, g.nx) + x0);
+            for (int q = 0; q < 9; ++q) row_load<T, V>(d.v[q], rowp(f, plane, q, y, g.nx), row_bytes, xoff);
         } else {
             // pull-push.cpp:13-21.  Lid scenes load the wall rows like any other row (the row
             // beyond the wall is the wall row itself, clamped) and fetch what the walls reflect
             // when the row is used (iteration_of): tests here would cost every row scalar work.
-            load_a<T, V>(d.v[7], rowp(f, plane, 7, yu, g.nx) + x0);
-            load_a<T, V>(d.v[4], rowp(f, plane, 4, yu, g.nx) + x0);
-            load_a<T, V>(d.v[8], rowp(f, plane, 8, yu, g.nx) + x0);
-            load_a<T, V>(d.v[3], rowp(f, plane, 3, y, g.nx) + x0);
-            load_a<T, V>(d.v[0], rowp(f, plane, 0, y, g.nx) + x0);
-            load_a<T, V>(d.v[1], rowp(f, plane, 1, y, g.nx) + x0);
-            load_a<T, V>(d.v[6], rowp(f, plane, 6, yd, g.nx) + x0);
-            load_a<T, V>(d.v[2], rowp(f, plane, 2, yd, g.nx) + x0);
-            load_a<T, V>(d.v[5], rowp(f, plane, 5, yd, g.nx) + x0);
+            row_load<T, V>(d.v[7], rowp(f, plane, 7, yu, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[4], rowp(f, plane, 4, yu, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[8], rowp(f, plane, 8, yu, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[3], rowp(f, plane, 3, y, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[0], rowp(f, plane, 0, y, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[1], rowp(f, plane, 1, y, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[6], rowp(f, plane, 6, yd, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[2], rowp(f, plane, 2, yd, g.nx), row_bytes, xoff);
+            row_load<T, V>(d.v[5], rowp(f, plane, 5, yd, g.nx), row_bytes, xoff);
             if (LID && wall_wave) {
                 // per-lane addresses keep these on the vector memory path next to the row loads
                 d.w[0] = rowp(f, plane, 6, y, g.nx)[x0];
@@ -401,7 +463,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // iteration instead of being copied.  Measured at 16384^2 fp32: with two register rings K=4 runs
     // as fast as with all rings in registers and K=5/6 become possible (K=6: +12 %); with three
     // register rings the pull kernels of K>=5 spill.
-    constexpr int kRegRings = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
+    constexpr int kRegRings = fused_reg_rings<T, V, PUSH, LID, AOS, ARITH>();
     constexpr int NLDS = NG > kRegRings ? NG - kRegRings : 0;
     constexpr int NREG = NG - NLDS > 0 ? NG - NLDS : 1;
     typedef typename VecTypes<T, V>::vec_t ring_vec_t;
@@ -556,14 +618,18 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                 relax_row<T, V, ARITH>(o, c, om);
             }
         }
-        if (i >= (uint32_t)(D + NG) && store_lane) {
-            const uint32_t yo = ys + i - (D + NG);
-            if (AOS) {
+        if (AOS) {
+            if (i >= (uint32_t)(D + NG) && i < iters && store_lane) {
+                const uint32_t yo = ys + i - (D + NG);
                 store_aos<T, V>(buf + ((size_t)yo * g.nx + x0) * 9, o);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) store_a<T, V>(rowp(buf, plane, q, yo, g.nx) + x0, o[q]);
             }
+        } else {
+            // no branch: the descriptor drops what must not be stored
+            const bool stores = i >= (uint32_t)(D + NG) && i < iters;
+            const uint32_t yo = stores ? ys + i - (D + NG) : ys;
+            const uint32_t bytes = stores ? row_bytes : 0u;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) row_store<T, V>(rowp(buf, plane, q, yo, g.nx), bytes, xoff_store, o[q]);
         }
     };
     // Lid scenes: one wave-uniform test per iteration picks the code.  Walls take part if the
@@ -594,16 +660,21 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 #pragma unroll
     for (int j = 0; j <= PF; ++j) { in[j].w[0] = T(0); in[j].w[1] = T(0); }
 #pragma unroll
-    for (int j = 0; j < PF; ++j)
-        if ((uint32_t)j < iters) load_row(in[j]);
-    for (uint32_t i0 = 0; i0 < iters; i0 += PF + 1) {
+    for (int j = 0; j < PF; ++j) load_row(in[j]);
+    // Nothing in the loop body is conditional but the stores: the request for row i + PF always goes
+    // out (the last PF requests of a segment fetch rows that nobody uses, clamped or wrapped into the
+    // array like every row index), and the trip count is rounded up to whole groups of PF + 1
+    // iterations (a surplus iteration computes a row outside the dependency cone and stores nothing).
+    // Under a condition the loaded registers meet their old values in a phi, and the compiler moves
+    // the first shuffles of the next iteration up into the block of the loads -- behind an
+    // s_waitcnt vmcnt(0) that stalls the wavefront on the rows it has just asked for, every
+    // iteration (or, for a conditional second half, on the stores it has just issued).
+    const uint32_t iters_up = (iters + PF) / (PF + 1) * (PF + 1);
+    for (uint32_t i0 = 0; i0 < iters_up; i0 += PF + 1) {
 #pragma unroll
         for (int j = 0; j <= PF; ++j) {
-            const uint32_t i = i0 + j;
-            if (i < iters) {
-                if (i + PF < iters) load_row(in[(j + PF) % (PF + 1)]);
-                iteration(in[j], i);
-            }
+            load_row(in[(j + PF) % (PF + 1)]);
+            iteration(in[j], i0 + j);
         }
     }
 }

@@ -58,7 +58,7 @@ class Simulation:
         self.f = torch.empty(ops.population_shape(self.nx, self.ny), dtype=dtype, device=self.device)
         self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
         self.t = 0
-        self.launches = 0   # sweep launches so far (a launch advances 1..6 steps)
+        self.launches = 0   # sweep launches so far (a launch advances 1..8 steps)
         self.launch_steps = []   # steps taken by each of the most recent launches (bounded)
         self._vel: Optional[torch.Tensor] = None
         self._mag: Optional[torch.Tensor] = None

@@ -164,9 +164,10 @@ def test_limits():
     # a run is cut into equal launches of at most eight steps
     big = torch.zeros((9, 4096, 4096), dtype=torch.float32, device="cuda")
     assert ops.plan_steps(big, 4096, 100) <= 8
+    assert ops.plan_steps(big, 4096, 20) == 7 and ops.plan_steps(big, 4096, 13) == 7 and ops.plan_steps(big, 4096, 6) == 6
     with ops.arithmetic("unrolled"):
-        assert ops.plan_steps(big, 4096, 20) == 5 and ops.plan_steps(big, 4096, 500) == 6
-        assert ops.plan_steps(big, 4096, 7) == 4 and ops.plan_steps(big, 4096, 3) == 3
+        assert ops.plan_steps(big, 4096, 20) == 7 and ops.plan_steps(big, 4096, 500) == 7
+        assert ops.plan_steps(big, 4096, 9) == 5 and ops.plan_steps(big, 4096, 3) == 3
 
 
 @pytest.mark.parametrize("scene,scheme", list(ONE_STEP))

@@ -53,7 +53,7 @@ SIZES = [(8, 3), (8, 1), (64, 48), (112, 9), (114, 7), (1024, 70), (2048, 5), (4
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scene,scheme", list(ONE_STEP))
-@pytest.mark.parametrize("k", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6, 7, 8])
 def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
     from lbm_amd import ops
     rng = np.random.default_rng(7 * k + (dtype == np.float64))
@@ -74,7 +74,7 @@ def test_whole_lattice_matches_k_oracle_steps(dtype, scene, scheme, k):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scheme", ["pull", "push"])
-@pytest.mark.parametrize("k", [2, 3, 4, 6])
+@pytest.mark.parametrize("k", [2, 3, 4, 6, 7, 8])
 def test_periodic_row_range_with_deep_ghost_rows(dtype, scheme, k):
     """wrap_y = 0: rows [k, ny-k) advance from an array whose outer k rows are ghost rows; rows
     outside the range must not be written."""
@@ -92,7 +92,7 @@ def test_periodic_row_range_with_deep_ghost_rows(dtype, scheme, k):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scheme", ["pull", "push"])
-@pytest.mark.parametrize("k", [2, 4, 5, 6])
+@pytest.mark.parametrize("k", [2, 4, 5, 6, 7, 8])
 def test_lid_slab_of_a_taller_cavity(dtype, scheme, k):
     """A slab holds global rows [g0 - ghosts, g1 + ghosts) of a cavity of height 40; slabs at the
     bottom wall, in the middle and under the lid."""
@@ -122,19 +122,19 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
     want = np.zeros_like(f)
     orc.pull_periodic_no_mpi(f, want, np.float32(0.7))
     assert_bits_equal(d_b.cpu().numpy(), want, "nsteps=1")
-    assert ops.fused_max_steps(d_f) == 6
+    assert ops.fused_max_steps(d_f) == 8
     odd = torch.zeros((9, 4, 67), dtype=torch.float64, device="cuda")
-    assert ops.fused_max_steps(odd) == 6      # one fp64 node per lane: any row length
+    assert ops.fused_max_steps(odd) == 8      # one fp64 node per lane: any row length
     odd = torch.zeros((9, 4, 66), dtype=torch.float32, device="cuda")
-    assert ops.fused_max_steps(odd) == 6
+    assert ops.fused_max_steps(odd) == 8
     odd = torch.zeros((9, 4, 67), dtype=torch.float32, device="cuda")
-    assert ops.fused_max_steps(odd) == 6      # odd rows in fp32: one node per lane
+    assert ops.fused_max_steps(odd) == 8      # odd rows in fp32: one node per lane
     one = torch.zeros((9, 4, 1), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(one) == 1
     with pytest.raises(capi.LbmError):
         ops.pull_periodic_fused(one, torch.zeros_like(one), 0.7, 0, 4, True, 2)     # unsupported row length
     with pytest.raises(capi.LbmError):
-        ops.pull_periodic_fused(d_f, d_b, 0.7, 0, 12, True, 7)                      # too many steps
+        ops.pull_periodic_fused(d_f, d_b, 0.7, 0, 12, True, 9)                      # too many steps
     with pytest.raises(capi.LbmError):
         ops.push_periodic_fused(d_f, d_b, 0.7, 1, 11, False, 2)                     # ghost rows too shallow
     with pytest.raises(capi.LbmError):
@@ -146,24 +146,25 @@ def test_one_step_is_forwarded_and_bad_arguments_are_rejected():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_extreme_aspect_ratios_fused_equals_one_step(dtype):
     """Very long rows (thousands of strips) and very tall, narrow lattices (thousands of segments):
-    six fused steps against six launches of the one-step sweeps, which the oracle tests pin."""
+    six and eight fused steps against as many launches of the one-step sweeps, which the oracle tests pin."""
     from lbm_amd import ops
     gen = torch.Generator(device="cuda").manual_seed(11)
     for nx, ny in ((262144, 20), (6, 50000), (131070, 7)):
         f = 1.0 / 9 + 0.02 * torch.randn((9, ny, nx), dtype=dtype, device="cuda", generator=gen)
         for scene in ("shear", "lid"):
             for scheme in ("pull", "push"):
-                a, b = f.clone(), torch.empty_like(f)
-                for _ in range(6):
+                for k in (6, 8):
+                    a, b = f.clone(), torch.empty_like(f)
+                    for _ in range(k):
+                        if scene == "shear":
+                            getattr(ops, f"{scheme}_periodic_no_mpi")(a, b, nx, ny, 1.2)
+                        else:
+                            getattr(ops, f"{scheme}_lid_driven")(a, b, nx, ny, 1.2, 1.0, 0.1)
+                        a, b = b, a
+                    got = torch.full_like(f, float("nan"))
                     if scene == "shear":
-                        getattr(ops, f"{scheme}_periodic_no_mpi")(a, b, nx, ny, 1.2)
+                        getattr(ops, f"{scheme}_periodic_fused")(f, got, 1.2, 0, ny, True, k)
                     else:
-                        getattr(ops, f"{scheme}_lid_driven")(a, b, nx, ny, 1.2, 1.0, 0.1)
-                    a, b = b, a
-                got = torch.full_like(f, float("nan"))
-                if scene == "shear":
-                    getattr(ops, f"{scheme}_periodic_fused")(f, got, 1.2, 0, ny, True, 6)
-                else:
-                    getattr(ops, f"{scheme}_lid_fused")(f, got, 1.2, 1.0, 0.1, 0, ny, 0, ny, 6)
-                bits = torch.int32 if dtype == torch.float32 else torch.int64
-                assert bool((got.view(bits) == a.view(bits)).all()), (scene, scheme, nx, ny)
+                        getattr(ops, f"{scheme}_lid_fused")(f, got, 1.2, 1.0, 0.1, 0, ny, 0, ny, k)
+                    bits = torch.int32 if dtype == torch.float32 else torch.int64
+                    assert bool((got.view(bits) == a.view(bits)).all()), (scene, scheme, nx, ny, k)

@@ -73,7 +73,7 @@ def test_one_step_entry_points(dtype, scheme):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scheme", ["pull", "push"])
-@pytest.mark.parametrize("k", [1, 2, 4, 6])
+@pytest.mark.parametrize("k", [1, 2, 4, 6, 7, 8])
 def test_several_steps_per_call(dtype, scheme, k):
     from lbm_amd import ops
     rng = np.random.default_rng(40 + k)
@@ -90,7 +90,7 @@ def test_limits_and_what_ignores_the_switch():
     from lbm_amd import capi, ops
     odd = torch.zeros((9, 6, 67), dtype=torch.float32, device="cuda")
     assert ops.fused_max_steps(odd) == 1                       # fp32 rows of an odd length: one step per call
-    assert ops.fused_max_steps(torch.zeros((9, 6, 67), dtype=torch.float64, device="cuda")) == 6
+    assert ops.fused_max_steps(torch.zeros((9, 6, 67), dtype=torch.float64, device="cuda")) == 8
     with pytest.raises(capi.LbmError, match="unsupported"):
         ops.pull_periodic_fused(odd, torch.zeros_like(odd), 0.7, 0, 6, True, 2)
     with ops.layout("aos"):
