@@ -18,11 +18,26 @@ What differs from the reference, on purpose:
   * blocks are initialised from the global row index; the reference's own offset
     (main.cpp:144) is wrong for ranks that do not sit in the bottom row of the grid.
 
-Only the pull scheme of the periodic scene runs here, as in the reference, whose lid-driven
-cavity refuses to run under MPI (main.cpp:317-319).  For one node of GPUs the y-slab path
-(lbm_amd.slab) is the fast one -- it keeps rows whole, so its sweeps are the vectorised and
-multi-step kernels; this module exists for lattices cut in both directions and is bit-identical
-to the single-device result.
+Both streaming schemes of the periodic scene run here (the reference's lid-driven cavity refuses to
+run under MPI, main.cpp:317-319), one time step per exchange:
+
+  pull   exchange halos of f || pull_periodic_inner, then pull_periodic_outer, swap (as above);
+  push   push_periodic_inner and push_periodic_outer scatter into buf including its halo ring; what
+         landed in the ring has left the block and is *returned* to the neighbours: the halo column
+         x = 0 (the populations that move in -x) goes to the left neighbour's last owned column,
+         x = nx+1 to the right neighbour's first, over the full height so that the corner
+         travellers ride along; then the halo rows to the lower / upper neighbours' edge rows.  The
+         return of step t overlaps push_periodic_inner of step t+1, which reads no edge node.
+         The reference's own push under MPI packs the edge populations of the pull scheme
+         (main.cpp:238-261) and is not a correct exchange for it; this one is bit-identical to the
+         single-device push run.
+
+For one node of GPUs the y-slab path (lbm_amd.slab, and `main -gpus N`) is the supported fast
+decomposition: it keeps rows whole, so its sweeps are the vectorised multi-step kernels with
+ghost rows as deep as a block of steps.  This module is the drop-in for the reference's
+inner / outer operators on lattices cut in both directions; it stays at one step per exchange
+(blocks of k steps would need k-deep halos in x as well, which the row-oriented multi-step
+kernels do not take).
 
 Kernels are reached through a small backend object so that the schedule can be exercised on CPU
 ranks in tests; the default backend is the HIP operator layer and refuses CPU tensors.
@@ -77,16 +92,26 @@ class HipCartBackend:
     def pull_outer(self, f, buf, om):
         self.ops.pull_periodic_outer(f, buf, om, f.shape[2], f.shape[1])
 
+    def push_inner(self, f, buf, om, LX, LY, HX, HY):
+        self.ops.push_periodic_inner(f, buf, om, LX, LY, HX, HY)
+
+    def push_outer(self, f, buf, om):
+        self.ops.push_periodic_outer(f, buf, om, f.shape[2], f.shape[1])
+
     def compute_velocities(self, vel, f, y_lo, y_hi):
         self.ops.compute_velocities(vel, f, 0, y_lo, f.shape[2], y_hi)
 
 
 class CartSimulation:
-    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull scheme."""
+    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull or push scheme."""
 
     def __init__(self, nx_glob: int, ny_glob: int, dtype: torch.dtype = torch.float32, omega: float = 0.5,
                  rho: float = 1.0, u: float = 0.1, device="cuda:0", backend=None,
-                 dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True):
+                 dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True, scheme: str = "pull"):
+        if scheme not in ("pull", "push"):
+            raise ValueError(f"unknown scheme {scheme!r}")
+        self.scheme = scheme
+        self._outflow_pending = False   # push: the halo ring of f holds what the last step pushed out of the block
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.backend = backend if backend is not None else HipCartBackend()
@@ -117,8 +142,10 @@ class CartSimulation:
         self.backend.init_shearwave(self.f, float(rho), float(u), self.y_below, self.ny_glob)
         self._idx = {name: torch.tensor(ch, dtype=torch.long, device=self.device)
                      for name, ch in (("R", RIGHT_MOVERS), ("L", LEFT_MOVERS), ("U", UP_MOVERS), ("D", DOWN_MOVERS))}
-        self._col = [torch.empty((3, self.ny), dtype=dtype, device=self.device) for _ in range(2)]
-        self._row = [torch.empty((3, self.nx + 2), dtype=dtype, device=self.device) for _ in range(2)]
+        # pull: owned height / full width; push: full height (corner travellers) / owned width
+        col_len, row_len = (self.ny, self.nx + 2) if scheme == "pull" else (self.ny + 2, self.nx)
+        self._col = [torch.empty((3, col_len), dtype=dtype, device=self.device) for _ in range(2)]
+        self._row = [torch.empty((3, row_len), dtype=dtype, device=self.device) for _ in range(2)]
         self._vel: Optional[torch.Tensor] = None
         # a second stream only where the exchange is stream-ordered (RCCL, or copies within the
         # rank); under the rehearsal transport the exchange blocks the host anyway
@@ -180,9 +207,53 @@ class CartSimulation:
         f[U, 0, :] = self._row[0]
         f[D, ny + 1, :] = self._row[1]
 
+    def _return_outflow(self) -> None:
+        """Push scheme: what the last step scattered into the halo ring of f goes to the neighbours'
+        edge nodes (the reverse of _exchange).  Columns over the full height first -- the entries in
+        the halo rows are the corner travellers, which the row phase then forwards."""
+        f, nx, ny = self.f, self.nx, self.ny
+        cx, cy = self.coords
+        R, L, U, D = (self._idx[k] for k in "RLUD")
+        out_right = f[R, :, nx + 1]
+        out_left = f[L, :, 0]
+        self._swap(out_right, out_left, self._col[0], self._col[1], self._rank_at(cx + 1, cy), self._rank_at(cx - 1, cy))
+        f[R, :, 1] = self._col[0]          # what my left neighbour pushed to the right arrives in my first column
+        f[L, :, nx] = self._col[1]
+        out_up = f[U, ny + 1, 1:nx + 1]
+        out_down = f[D, 0, 1:nx + 1]
+        self._swap(out_up, out_down, self._row[0], self._row[1], self._rank_at(cx, cy + 1), self._rank_at(cx, cy - 1))
+        f[U, 1, 1:nx + 1] = self._row[0]
+        f[D, ny, 1:nx + 1] = self._row[1]
+        self._outflow_pending = False
+
+    def _complete(self) -> None:
+        """Make f the complete state of time t (push: collect the outflow of the last step)."""
+        if self._outflow_pending:
+            self._return_outflow()
+
+    def _step_push(self) -> None:
+        NX, NY = self.nx + 2, self.ny + 2
+        if self.overlap and self._outflow_pending:
+            main = torch.cuda.current_stream(self.device)
+            self._comm.wait_stream(main)
+            self.backend.push_inner(self.f, self.buf, self.omega, 2, 2, NX - 2, NY - 2)
+            with torch.cuda.stream(self._comm):
+                self._return_outflow()
+            main.wait_stream(self._comm)
+        else:
+            self._complete()
+            self.backend.push_inner(self.f, self.buf, self.omega, 2, 2, NX - 2, NY - 2)
+        self.backend.push_outer(self.f, self.buf, self.omega)
+        self.f, self.buf = self.buf, self.f
+        self._outflow_pending = True
+        self.t += 1
+
     # ---- one time step (main.cpp:217-398) ------------------------------------------------------
     def step(self, nsteps: int = 1) -> None:
         for _ in range(int(nsteps)):
+            if self.scheme == "push":
+                self._step_push()
+                continue
             NX, NY = self.nx + 2, self.ny + 2
             if self.overlap:
                 # the exchange waits for the previous step only, not for the inner sweep launched
@@ -203,6 +274,7 @@ class CartSimulation:
     # ---- outputs --------------------------------------------------------------------------------
     def velocities(self) -> torch.Tensor:
         """ux, uy of the owned nodes: [2, ny, nx]."""
+        self._complete()
         if self._vel is None:
             self._vel = torch.empty((2, self.ny, self.nx + 2), dtype=self.f.dtype, device=self.device)
         self.backend.compute_velocities(self._vel, self.f, 1, self.ny + 1)
@@ -222,6 +294,7 @@ class CartSimulation:
 
     def interior(self) -> torch.Tensor:
         """The owned nodes without the halo: [9, ny, nx] (a view)."""
+        self._complete()
         return self.f[:, 1:self.ny + 1, 1:self.nx + 1]
 
     def gather_populations(self) -> Optional[torch.Tensor]:

@@ -64,6 +64,7 @@ struct Options {
     SceneType scene = SHEAR_WAVE;
     std::string file;
     bool use_file = false;
+    unsigned gpus = 0;   // y-slabs (0 = not given): -gpus N, else LBM_GPUS, else every device when USE_MPI is set
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -94,7 +95,8 @@ static const char *kUsage =
     "  -ovf, --output-velocity-field If specified, the program outputs the components of the velocity field at each node as #-seperated CSV tables of NY columns and NX rows, first all x-components, then all y-components \n"
     "  -f, --file                    Specify a filename to write to instead of printing output to std::cout \n"
     "  -sw, --shear-wave-decay       Simulate a shear-wave decay with velocities in x-direction and periodic boundaries. This is the default. \n"
-    "  -ld, --lid-driven-cavity      Simulate a lid driven cavity with bounce-back solid walls and a moving wall at the top, where the fluid is initially at rest. \n";
+    "  -ld, --lid-driven-cavity      Simulate a lid driven cavity with bounce-back solid walls and a moving wall at the top, where the fluid is initially at rest. \n"
+    "  -gpus, --gpus                 (not in the reference, which is started under mpirun) Cut the lattice into this many y-slabs, one per GPU of this node; the environment variable LBM_GPUS does the same \n";
 
 static UINT parse_uint(const std::string &s)
 {
@@ -166,6 +168,7 @@ static Options parse_args(int argc, char **argv)
         else if (a == "-f" || a == "--file") { o.file = value(); o.use_file = true; }
         else if (a == "-sw" || a == "--shear-wave-decay") { exclusive(first_scene, "-sw/--shear-wave-decay"); o.scene = SHEAR_WAVE; }
         else if (a == "-ld" || a == "--lid-driven-cavity") { exclusive(first_scene, "-ld/--lid-driven-cavity"); o.scene = LID_DRIVEN; }
+        else if (a == "-gpus" || a == "--gpus") o.gpus = (unsigned)parse_uint(value());   // not a flag of the reference (it runs under mpirun -n)
         else throw std::runtime_error("Unknown argument: " + a);
     }
     return o;
@@ -377,12 +380,10 @@ static bool run_simulation(Run &r)
     return true;
 }
 
+#include "slabs.h"
+
 int main(int argc, char *argv[])
 {
-#if USE_MPI
-    std::cerr << "note: USE_MPI is set in src/macros.h; this driver runs one GPU per process and has no MPI path "
-                 "(multi-GPU runs use the y-slab decomposition of the lbm_amd package)" << std::endl;
-#endif
     Run r;
 #if !COALESCING
     // macros.h:7 / global.h:37-41: f and buf are [NY][NX][9] for the whole run
@@ -418,8 +419,28 @@ int main(int argc, char *argv[])
     die_hip(hipFree(nullptr), "HIP runtime start-up");
     die_hip(hipStreamCreate(&r.stream), "stream");
 
+    // How many y-slabs: -gpus N, else LBM_GPUS=N; a build with USE_MPI set (the reference's multi-rank
+    // build, macros.h:8, started there as `mpirun -n N ./main`) takes every visible device.  One slab
+    // is the single-device path.
+    unsigned nslabs = r.o.gpus;
+    if (nslabs == 0) {
+        const char *e = std::getenv("LBM_GPUS");
+        if (e && *e) nslabs = (unsigned)std::strtoul(e, nullptr, 10);
+    }
+#if USE_MPI
+    if (nslabs == 0) {
+        int ndev = 1;
+        die_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        nslabs = (unsigned)ndev;
+    }
+#endif
+    if (nslabs > 1 && lbm_get_layout() != LBM_LAYOUT_SOA) {
+        std::cerr << "the y-slab decomposition runs on [9][NY][NX] arrays only (COALESCING=true)" << std::endl;
+        return 1;
+    }
+
     const auto start = std::chrono::high_resolution_clock::now();
-    const bool success = run_simulation(r);
+    const bool success = nslabs > 1 ? run_simulation_slabs(r, nslabs) : run_simulation(r);
     // the reference stops its clock without a fence (main.cpp:428); here every kernel has finished
     die_hip(hipDeviceSynchronize(), "sync");
     const auto end = std::chrono::high_resolution_clock::now();

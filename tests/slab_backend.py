@@ -106,5 +106,13 @@ class OracleCartBackend:
         a = f.numpy()
         orc.pull_periodic_outer(a, buf.numpy(), a.dtype.type(om))
 
+    def push_inner(self, f, buf, om, LX, LY, HX, HY):
+        a = f.numpy()
+        orc.push_periodic_inner(a, buf.numpy(), a.dtype.type(om), LX, LY, HX, HY)
+
+    def push_outer(self, f, buf, om):
+        a = f.numpy()
+        orc.push_periodic_outer(a, buf.numpy(), a.dtype.type(om))
+
     def compute_velocities(self, vel, f, y_lo, y_hi):
         vel.numpy()[...] = orc.compute_velocities(f.numpy(), y_lo, y_hi)

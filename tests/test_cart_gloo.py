@@ -37,14 +37,15 @@ def _worker(rank, world, dims, store_path, out_path):
     results = {}
     try:
         for (tdt, nx, ny, steps, omega) in CASES:
-            sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cpu",
-                                 backend=OracleCartBackend(), dims=dims)
-            vmax0 = sim.max_velocity()
-            sim.step(steps)
-            vmax = sim.max_velocity()
-            full = sim.gather_populations()
-            if rank == 0:
-                results[(tdt, nx, ny, steps, omega)] = (full.numpy().copy(), vmax0, vmax)
+            for scheme in ("pull", "push"):
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cpu",
+                                     backend=OracleCartBackend(), dims=dims, scheme=scheme)
+                vmax0 = sim.max_velocity()
+                sim.step(steps)
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[(tdt, nx, ny, steps, omega, scheme)] = (full.numpy().copy(), vmax0, vmax)
         if rank == 0:
             torch.save(results, out_path)
     finally:
@@ -69,12 +70,12 @@ def test_blocks_reproduce_the_single_domain_run(world, dims):
         store, out = os.path.join(tmp, "store"), os.path.join(tmp, "out.pt")
         mp.spawn(_worker, args=(world, dims, store, out), nprocs=world, join=True)
         results = torch.load(out, weights_only=False)
-    for (tdt, nx, ny, steps, omega), (full, vmax0, vmax) in results.items():
+    for (tdt, nx, ny, steps, omega, scheme), (full, vmax0, vmax) in results.items():
         dtype = getattr(np, tdt)
-        want, _ = orc.run("shear", "pull", nx, ny, steps, omega, dtype)
+        want, _ = orc.run("shear", scheme, nx, ny, steps, omega, dtype)
         assert full.dtype == want.dtype and full.shape == want.shape
         bits = np.uint32 if dtype == np.float32 else np.uint64
-        assert (full.view(bits) == want.view(bits)).all(), (world, dims, tdt, nx, ny)
+        assert (full.view(bits) == want.view(bits)).all(), (world, dims, tdt, nx, ny, scheme)
         start = orc.alloc(nx, ny, dtype)
         orc.init_shearwave(start, dtype(1.0), dtype(0.1))
         assert vmax0 == float(orc.max_velocity(start))
@@ -86,10 +87,11 @@ def test_single_rank_wraps_onto_itself():
     from oracle import oracle as orc
     from lbm_amd.cart import CartSimulation
     from slab_backend import OracleCartBackend
-    sim = CartSimulation(9, 6, dtype=torch.float64, omega=1.1, device="cpu", backend=OracleCartBackend())
-    sim.step(17)
-    want, _ = orc.run("shear", "pull", 9, 6, 17, 1.1, np.float64)
-    assert (sim.gather_populations().numpy().view(np.uint64) == want.view(np.uint64)).all()
+    for scheme in ("pull", "push"):
+        sim = CartSimulation(9, 6, dtype=torch.float64, omega=1.1, device="cpu", backend=OracleCartBackend(), scheme=scheme)
+        sim.step(17)
+        want, _ = orc.run("shear", scheme, 9, 6, 17, 1.1, np.float64)
+        assert (sim.gather_populations().numpy().view(np.uint64) == want.view(np.uint64)).all(), scheme
     with pytest.raises(RuntimeError):
         CartSimulation(9, 6, device="cpu")       # the default kernels are HIP-only
     with pytest.raises(ValueError):

@@ -22,14 +22,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("overlap", [True, False])
-def test_one_rank_equals_the_oracle(dtype, overlap):
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+def test_one_rank_equals_the_oracle(dtype, overlap, scheme):
     from lbm_amd.cart import CartSimulation
     npdt = np.float32 if dtype == torch.float32 else np.float64
     for nx, ny, steps, omega in ((64, 48, 40, 0.8), (131, 37, 25, 1.4), (2, 2, 9, 1.0), (1024, 300, 12, 0.5)):
-        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap)
+        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap, scheme=scheme)
         sim.step(steps)
-        want, _ = orc.run("shear", "pull", nx, ny, steps, omega, npdt)
-        assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 {nx}x{ny}")
+        want, _ = orc.run("shear", scheme, nx, ny, steps, omega, npdt)
+        assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 {scheme} {nx}x{ny}")
         assert sim.max_velocity() == float(orc.max_velocity(want))
         assert sim.t == steps
 
@@ -46,12 +47,13 @@ def _worker(rank, world, store_path, out_path):
     try:
         for case in CASES:
             tdt, nx, ny, steps, omega = case
-            sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0")
-            sim.step(steps)
-            vmax = sim.max_velocity()
-            full = sim.gather_populations()
-            if rank == 0:
-                results[case] = (full.cpu().numpy(), vmax, sim.dims)
+            for scheme in ("pull", "push"):
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0", scheme=scheme)
+                sim.step(steps)
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[case + (scheme,)] = (full.cpu().numpy(), vmax, sim.dims)
         if rank == 0:
             torch.save(results, out_path)
     finally:
@@ -65,8 +67,8 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world):
         out = os.path.join(tmp, "out.pt")
         mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), out), nprocs=world, join=True)
         results = torch.load(out, weights_only=False)
-    for (tdt, nx, ny, steps, omega), (full, vmax, dims) in results.items():
+    for (tdt, nx, ny, steps, omega, scheme), (full, vmax, dims) in results.items():
         assert dims == ((2, 2) if world == 4 else (3, 2))
-        want, _ = orc.run("shear", "pull", nx, ny, steps, omega, getattr(np, tdt))
-        assert_bits_equal(full, want, f"cart {dims} {tdt} {nx}x{ny}")
+        want, _ = orc.run("shear", scheme, nx, ny, steps, omega, getattr(np, tdt))
+        assert_bits_equal(full, want, f"cart {dims} {scheme} {tdt} {nx}x{ny}")
         assert vmax == float(orc.max_velocity(want))

@@ -175,3 +175,31 @@ def test_double_precision_build(golden_dir):
         for c in range(2):
             want += "\n".join(",".join(orc.fmt(v) for v in r) for r in vel[c]) + "\n#\n"
     assert p.stdout == want
+
+
+@pytest.mark.gpu
+def test_y_slabs_print_what_one_device_prints():
+    """-gpus N (or LBM_GPUS=N): the lattice cut into N y-slabs driven by the one process, as the
+    reference runs under `mpirun -n N` (main.cpp:92-401).  More slabs than devices share the devices,
+    so one GPU exercises the whole schedule: same text as the single-slab run, for the periodic and
+    the cavity scene, pull and push, slab heights that differ by a row, all three outputs."""
+    cases = [("-nx", 256, "-ny", 203, "-w", 0.8, "-s", 1001, "-of", 100, "-omv"),
+             ("-nx", 256, "-ny", 203, "-w", 0.8, "-s", 1001, "-of", 100, "-omv", "-push"),
+             ("-nx", 96, "-ny", 70, "-w", 1.2, "-s", 201, "-of", 100, "-ovf", "-ld"),
+             ("-nx", 64, "-ny", 61, "-w", 1.0, "-s", 50, "-of", 7, "-ov"),
+             ("-nx", 1024, "-ny", 2048, "-w", 0.5, "-s", 300, "-of", 50, "-omv")]
+    for args in cases:
+        one = run_main(*args)
+        for n in (2, 3, 7):
+            p = run_main(*args, "-gpus", n)
+            assert p.stdout == one.stdout, (args, n)
+            lines = p.stderr.split("\n")
+            assert lines[1].startswith(f"{n} y-slab(s) of "), lines[:3]
+            nx, ny, steps = args[1], args[3], args[7]
+            check_stderr_contract(p.stderr, nx, ny, steps)
+    # the environment variable does the same; slabs thinner than two rows are refused
+    env = dict(os.environ, LBM_GPUS="4")
+    p = subprocess.run(["./main", *map(str, cases[0])], cwd=BUILD, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout == run_main(*cases[0]).stdout and "4 y-slab(s)" in p.stderr
+    p = run_main("-nx", 64, "-ny", 9, "-s", 4, "-gpus", 8, check=False)
+    assert p.returncode == 1 and "too thin" in p.stderr
