@@ -401,7 +401,9 @@ def main():
                 "ny_per_gpu": ny_loc, "omega": args.omega,
                 "decomposition": ("single device" if world == 1 and not args.slab else
                                   f"{world} y-slab(s), {sim.G} ghost row(s) per edge refreshed every "
-                                  f"{sim.G} step(s), RCCL send/recv"),
+                                  f"{sim.G} step(s), "
+                                  + ("RCCL" if (dist.is_initialized() and dist.get_backend() == "nccl") else "gloo (rehearsal)")
+                                  + " send/recv"),
                 "steps_per_launch": steps_per_launch,
                 "launch_plan": plan,
                 "warmup_steps_run": args.warmup + extra_warmup,
