@@ -531,10 +531,17 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         if (nstrips * ((rows + seg - 1) / seg) < 8 * slots) {
             small_grid = true;
+            // A wavefront alone on its SIMD finishes an iteration 1.6 x sooner than one that shares it
+            // (1024^2 fp32, six steps: 1.75 us against 3.0 us per iteration), so a last round that
+            // leaves every SIMD at most one wavefront is priced at 1.0 per iteration and a fuller one
+            // at 1.6: 1024^2 takes 12-row segments (860 wavefronts, 22 iterations) rather than 6-row
+            // ones (1710 wavefronts, 16 iterations), 119 -> 146 GLUPS.
+            const uint64_t simds = slots / 2;
             uint64_t best = ~0ull;
-            for (uint64_t s = 128; s >= 2; --s) {
+            for (uint64_t s = 186; s >= 2; --s) {
                 const uint64_t waves = nstrips * ((rows + s - 1) / s);
-                const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
+                const uint64_t full = waves / slots, rest = waves % slots;
+                const uint64_t cost = (full * 16 + (rest == 0 ? 0 : rest <= simds ? 10 : 16)) * (s + extra);
                 if (cost < best) { best = cost; seg = s; }
             }
         } else if (seg == 128) {
@@ -566,10 +573,12 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         const uint64_t iters = (seg + extra) * 5 / 6;          // iterations at 1.2 x the time each
         const uint64_t slots = wave_slots(), nwall = nstrips < 2 ? nstrips : 2;
         const uint64_t rounds = (nstrips * nsegs + slots - 1) / slots;
-        // the shortest segments that do not push the grid into another round of wavefronts
+        // the shortest segments that do not push the grid into another round of wavefronts -- nor,
+        // where every wavefront has a SIMD to itself, beyond one wavefront per SIMD
+        const uint64_t cap = nstrips * nsegs <= slots / 2 ? slots / 2 : rounds * slots;
         for (uint64_t s = iters > extra + 2 ? iters - extra : 2; s < seg; ++s) {
             const uint64_t nw = (rows + s - 1) / s;
-            if ((nstrips - nwall) * nsegs + nwall * nw <= rounds * slots) {
+            if ((nstrips - nwall) * nsegs + nwall * nw <= cap) {
                 seg_wall = s;
                 nsegs_wall = nw;
                 break;
@@ -1082,18 +1091,17 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     const char *e = getenv("LBM_FUSED_MIN_NODES");
     const uint64_t min_nodes = e ? strtoull(e, nullptr, 10) : 0ull;
     if (nx * rows < min_nodes) return 1;
-    // Five and six steps per launch pay off once the grid is large enough to keep the chip busy for
-    // the longer ramp of a wavefront (fp32 pull, GLUPS at 4 / 6 steps: 512^2 47 / 35, 1024^2 108 / 92,
-    // 1536^2 150 / 145, 2048^2 174 / 180, 4096^2 232 / 261, 8192^2 252 / 290, 16384^2 250 / 285).
-    // The smallest ones (fp32 pull, 3 / 4 steps: 256^2 17.1 / 16.7, 512^2 56 / 49, 1024^2 118 / 120) take three.
     // Large lattices (16384^2, GLUPS at 6/7/8 steps): fp32 strict 325/334/335, contracted 377/410/424
     // (push 372/401/411); fp64 contracted pull 162/167/171, push 159/166/162.  The strict and rolled
     // spellings and the fp64 sweeps take seven (an eighth step gains little or nothing and deepens
     // the halos of a decomposed run), contracted fp32 eight.
     uint64_t dflt = (uint64_t)kmax;
     if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
-    if (dflt > 4 && nx * rows < (3ull << 20)) dflt = 4;
-    if (dflt > 3 && nx * rows < 600000ull) dflt = 3;
+    // Small lattices (one round of wavefronts or less) are bound by the chain of dependent iterations
+    // of a wavefront; more steps lengthen the chain.  fp32 pull, GLUPS at 3/4/5/6/7/8 steps: 512^2
+    // 50/56/57/53/52/49, 1024^2 107/128/144/137/136/133, 1536^2 135/160/197/203/212/213, 2048^2
+    // 161/196/225/233/253/260.
+    if (dflt > 5 && nx * rows < (3ull << 19)) dflt = 5;
     const char *m = getenv("LBM_FUSED_MAX_STEPS");
     uint64_t k = m ? strtoull(m, nullptr, 10) : dflt;
     if (k < 1) k = 1;

@@ -89,14 +89,16 @@ template <typename T, int V, int K> constexpr int fused_halo_lanes()
 // periodic fp32 kernels have room for four (16384^2, eight steps: 2 rings 388 GLUPS, 3 rings 410,
 // 4 rings 412; push 344 / 388 / 411).  Everything else keeps two: the fp64 kernels spill a few
 // registers with three (and run 2 % faster all the same) and badly with four (171 -> 81 GLUPS), the
-// rolled arithmetic spills with four, the cavity kernels carry the wall cases in registers as well.
+// rolled arithmetic spills with four, the cavity kernels carry the wall cases in registers as well
+// (fp32 push: three fit, pull: two).
 // No instantiation of the library uses scratch memory.
 template <typename T, int V, bool PUSH, bool LID, bool AOS, int ARITH>
 constexpr int fused_reg_rings()
 {
     constexpr int forced = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
     if (forced > 0) return forced;
-    if (LID || AOS || ARITH == kArithRolled || sizeof(T) == 8) return 2;
+    if (AOS || ARITH == kArithRolled || sizeof(T) == 8) return 2;
+    if (LID) return PUSH ? 3 : 2;      // pull cavity kernels spill with three from six steps on
     return 4;
 }
 

@@ -69,8 +69,8 @@ def test_long_run_1000_steps(dtype, scene, scheme, monkeypatch):
     ref, _ = orc.run(scene, scheme, nx, ny, 1000, omega, dtype)
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
     sim.step(1000)
-    assert sim.launches == 334   # runs of three steps on a lattice this small
-    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 4")
+    assert sim.launches == 200   # runs of five steps on a lattice this small
+    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 5")
     # the same run with a size threshold that sends this lattice to the one-step sweeps
     monkeypatch.setenv("LBM_FUSED_MIN_NODES", "1000000")
     sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
