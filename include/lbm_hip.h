@@ -20,6 +20,10 @@
  *   - Pointers are device pointers on the current HIP device, 16-byte aligned.
  *   - Every function returns an lbm_status; nothing throws.  lbm_last_error() gives the detail of the
  *     calling thread's last failure.
+ *   - lbm_set_layout, lbm_set_unroll_loops / lbm_set_arithmetic and lbm_set_launch_shape are
+ *     process-wide settings (the reference's compile-time macros made run-time switches).  They are
+ *     atomic variables read once per call: set them before sweeps are issued from several threads;
+ *     a call in flight keeps the value it read.
  *   - x is always periodic inside a *_rows call (a slab spans the full NX); the reference's
  *     2-D halo forms (inner/outer) take explicit bounds and never wrap.
  */
@@ -220,8 +224,9 @@ int lbm_velocity_magnitudes(const void *f, void *mag, int prec, uint64_t nx, uin
                             uint64_t y_lo, uint64_t y_hi, void *stream);
 /* Replaces the MAX_VEL reduction of output() (io.cpp:184-208): max over rows [y_lo,y_hi) of
  * sqrtf(ux^2+uy^2), NaNs ignored, -1e30 when no node qualifies.  The result is written as one FLT
- * to out_dev (device memory, 8-byte aligned); asynchronous.  Uses a small per-device scratch word
- * the library allocates on first use: two calls overlapping on one device race. */
+ * to out_dev (device memory, 8-byte aligned); asynchronous.  The result word doubles as the
+ * reduction's scratch (it holds intermediate values until the call's last kernel has run), so the
+ * call allocates nothing and calls with different out_dev never interfere. */
 int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
                          uint64_t y_lo, uint64_t y_hi, void *stream);
 /* No counterpart in the reference.  lbm_max_velocity_dev for callers that cannot allocate device
@@ -237,7 +242,8 @@ int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, ui
 int lbm_max_velocity_dev_static(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,
                                 uint64_t y_lo, uint64_t y_hi, void *stream);
 /* Same as lbm_max_velocity_dev, result delivered to the host as double (exact widening of the FLT
- * value).  Synchronises the stream. */
+ * value).  Synchronises the stream.  Its device scratch is per host thread and device (allocated on
+ * the thread's first call), so concurrent calls from several threads do not interfere. */
 int lbm_max_velocity(const void *f, int prec, uint64_t nx, uint64_t ny, uint64_t y_lo,
                      uint64_t y_hi, void *stream, double *out_host);
 

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -43,7 +44,7 @@ int fail(int status, const char *fmt, ...)
     } while (0)
 
 // memory layout of every distribution array passed in (lbm_set_layout)
-int g_layout = LBM_LAYOUT_SOA;
+std::atomic<int> g_layout{LBM_LAYOUT_SOA};
 
 // spelling of the relaxation (lbm_set_arithmetic / lbm_set_unroll_loops): lbm::kArithUnrolled (default),
 // kArithRolled (the reference's UNROLL_LOOPS=false spelling; periodic sweeps only) or kArithContracted
@@ -54,11 +55,11 @@ int arithmetic_default()
     if (e && strcmp(e, "rolled") == 0) return lbm::kArithRolled;
     return lbm::kArithUnrolled;
 }
-int g_arith = arithmetic_default();
+std::atomic<int> g_arith{arithmetic_default()};
 
 // launch-shape hint (lbm_set_launch_shape)
-unsigned g_threads_x = 0;
-unsigned g_waves_per_cu = 0;
+std::atomic<unsigned> g_threads_x{0};
+std::atomic<unsigned> g_waves_per_cu{0};
 
 // Measured on MI355X (16384^2, straight-line sweeps, nt stores, 64-lane workgroups): the achieved
 // HBM rate is flat at 4-6 resident waves per CU (fp32 pull 6.06-6.13 TB/s), falls off a cliff at 7
@@ -854,19 +855,20 @@ int velocity_t(const void *f, void *out, uint64_t nx, uint64_t ny, uint64_t y_lo
     return launch_status("compute velocities");
 }
 
-// per-device scratch for the max-|u| key (one 256-byte line each), allocated on first use
+// Scratch of lbm_max_velocity (key word + decoded result, one 256-byte line): per device and per
+// host thread, allocated on a thread's first call on a device.  The call synchronises its stream
+// before it returns, so one thread never has two reductions in flight on a line, and two threads
+// never share one.  (lbm_max_velocity_dev needs no scratch: the result word itself is the key.)
 constexpr int kMaxDevices = 64;
-uint32_t *g_key[kMaxDevices] = {};
-std::mutex g_key_mutex;
+thread_local uint32_t *t_key[kMaxDevices] = {};
 
 int key_scratch(uint32_t **out)
 {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(LBM_ERR_NO_DEVICE, "device ordinal %d out of range", dev);
-    std::lock_guard<std::mutex> lock(g_key_mutex);
-    if (g_key[dev] == nullptr) HIP_TRY(hipMalloc((void **)&g_key[dev], 256));
-    *out = g_key[dev];
+    if (t_key[dev] == nullptr) HIP_TRY(hipMalloc((void **)&t_key[dev], 256));
+    *out = t_key[dev];
     return LBM_OK;
 }
 
@@ -1164,11 +1166,12 @@ int lbm_max_velocity_dev(const void *f, void *out_dev, int prec, uint64_t nx, ui
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
     if (out_dev == nullptr || (uintptr_t)out_dev % 8 != 0)
         return fail(LBM_ERR_INVALID_ARGUMENT, "result pointer must be non-null and 8-byte aligned");
-    uint32_t *key = nullptr;
-    if (int s = key_scratch(&key)) return s;
+    // the caller's result word doubles as the reduction's key (cleared, raised by atomicMax, decoded in
+    // place): no state shared between calls, nothing allocated
+    uint32_t *key = (uint32_t *)out_dev;
     hipStream_t st = (hipStream_t)stream;
-    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st)
-                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(uint32_t), st);
+    return prec == LBM_F32 ? max_velocity_t<float>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(float), st)
+                           : max_velocity_t<double>(f, out_dev, nx, ny, y_lo, y_hi, key, sizeof(double), st);
 }
 
 int lbm_max_velocity_dev_static(const void *f, void *out_dev, int prec, uint64_t nx, uint64_t ny,

@@ -1130,7 +1130,7 @@ k_max_speed(const T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_lo, ui
 
 // Decode the key into one FLT (start value -1e30 as io.cpp:184 when no node qualified).
 template <typename T>
-__global__ void k_max_speed_finish(const uint32_t *__restrict__ key, T *__restrict__ out)
+__global__ void k_max_speed_finish(const uint32_t *key, T *out)   // out may be the key's own address
 {
     const uint32_t k = *key;
     *out = (k == 0) ? (T)-1e30 : (T)__uint_as_float(k - 1u);
