@@ -132,7 +132,8 @@ int check_rows(uint64_t ny, uint64_t y_lo, uint64_t y_hi, bool needs_ghosts)
 
 unsigned pick_block(uint64_t lanes_per_row)
 {
-    unsigned b = g_threads_x ? g_threads_x : kDefaultThreadsX;
+    const unsigned tx = g_threads_x.load();
+    unsigned b = tx ? tx : kDefaultThreadsX;
     // do not launch workgroups much wider than a row
     while (b > 64 && (uint64_t)b / 2 >= lanes_per_row) b /= 2;
     return b;
@@ -153,7 +154,8 @@ size_t residency_ballast(unsigned block, size_t elem_size, bool pull, uint64_t n
     // both arrays resident in the 256 MiB Infinity Cache: the L2 cliff does not bite and more waves
     // hide more latency (1024^2 fp32: 66.3 GLUPS at 16-24 waves/CU against 64.5 at 6)
     const bool cache_resident = 2ull * 9ull * nx * ny * elem_size <= (192ull << 20);
-    const unsigned waves = g_waves_per_cu ? g_waves_per_cu
+    const unsigned wpc = g_waves_per_cu.load();
+    const unsigned waves = wpc ? wpc
                            : cache_resident ? kWavesPerCU_cache_resident
                            : (elem_size == 4 ? kWavesPerCU_f32 : (pull ? kWavesPerCU_f64_pull : kWavesPerCU_f64_push));
     const unsigned waves_per_block = block / 64;
