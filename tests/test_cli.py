@@ -203,3 +203,15 @@ def test_y_slabs_print_what_one_device_prints():
     assert p.returncode == 0 and p.stdout == run_main(*cases[0]).stdout and "4 y-slab(s)" in p.stderr
     p = run_main("-nx", 64, "-ny", 9, "-s", 4, "-gpus", 8, check=False)
     assert p.returncode == 1 and "too thin" in p.stderr
+    # the contracted arithmetic: slabs against one device, and
+    # one device against the oracle's restatement of the contraction
+    env = dict(os.environ, LBM_ARITHMETIC="contracted")
+    args = ("-nx", 512, "-ny", 300, "-w", 1.1, "-s", 401, "-of", 100, "-omv")
+    runs = [subprocess.run(["./main", *map(str, args), *extra], cwd=BUILD, capture_output=True, text=True, timeout=600, env=env)
+            for extra in ((), ("-gpus", "3"), ("-gpus", "5"))]
+    assert all(r.returncode == 0 for r in runs), [r.stderr for r in runs]
+    assert runs[1].stdout == runs[0].stdout and runs[2].stdout == runs[0].stdout
+    assert "3 y-slab(s) of 100 rows" in runs[1].stderr
+    with orc.arithmetic("contracted"):
+        _, s = orc.run("shear", "pull", 512, 300, 401, 1.1, np.float32, out_every=100)
+    assert runs[0].stdout == "".join(orc.fmt(v) + "," for v in s)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 numbers for the documents: the five baseline configurations in both arithmetics, the other layouts
+# Numbers for the documents: the five baseline configurations in both arithmetics, the other layouts
 # and spellings, the C++ slab driver.  Output: gpurun_out/r02_matrix.txt
 set -u
 OUT=$PWD/gpurun_out/r02_matrix.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 2, first GPU pass: whole GPU suite, the driver's bench command, the contracted arithmetic at
+# First GPU pass: whole GPU suite, the bench command as the driver issues it, the contracted arithmetic at
 # 6/7/8 steps per launch.  Every GPU step has its own time limit; the chain stops at the first failure.
 set -u
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 2 GPU pass: whole GPU suite, then the bench matrix in both arithmetics.
+# GPU pass: whole GPU suite, then the bench matrix in both arithmetics.
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/r02_step5
