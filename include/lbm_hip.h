@@ -71,8 +71,8 @@ int lbm_get_layout(void);
  * push_periodic_for (pull-push.cpp:77-120, :190-243; unrolled == 0), which round the equilibrium
  * differently (4.5*(c*c) instead of (4.5*c)*c) and so differ in the last bits.  Each is followed
  * literally.  The lid-driven sweeps have one spelling in the reference and ignore the switch.  With
- * unrolled == 0 the one-step periodic entry points run element-wise kernels, the *_fused ones the
- * multi-step kernels (fp32: rows of an even length >= 4); [NY][NX][9] arrays are not supported. */
+ * unrolled == 0 the *_fused entry points need fp32 rows of an even length >= 4, and [NY][NX][9]
+ * arrays are not supported. */
 int lbm_set_unroll_loops(int unrolled);
 int lbm_get_unroll_loops(void);
 
@@ -88,9 +88,8 @@ int lbm_get_unroll_loops(void);
  *                         reciprocal of the density (correctly rounded) and all other products are
  *                         unchanged.  A third fewer vector instructions per node.  Populations stay within the parity budget of
  *                         the unrolled spelling (fp32 1e-5, fp64 1e-12 max-abs over thousands of
- *                         steps; measured 2e-7 / 1e-15).  All sweeps on [9][NY][NX] arrays; the
- *                         one-step entry points run element-wise kernels.  fp32 rows must have an even
- *                         length >= 4 for the *_fused entry points.
+ *                         steps; measured 3e-7 / 1e-15).  All sweeps on [9][NY][NX] arrays; fp32 rows
+ *                         must have an even length >= 4 for the *_fused entry points.
  * The environment variable LBM_ARITHMETIC (unrolled | rolled | contracted) sets the initial value. */
 enum { LBM_ARITH_UNROLLED = 0, LBM_ARITH_ROLLED = 1, LBM_ARITH_CONTRACTED = 2 };
 int lbm_set_arithmetic(int arithmetic);

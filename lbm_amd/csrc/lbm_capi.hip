@@ -218,8 +218,8 @@ const char *const kAosNoHalo =
     "the x-halo'd inner/outer forms exist only for [9][NY][NX] arrays (the reference's MPI path too, main.cpp:147)";
 
 // ---- periodic sweeps -------------------------------------------------------------------
-template <typename T, bool PULL>
-int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_,
+template <typename T, bool PULL, int ARITH>
+int sweep_periodic_rows_as(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_,
                         uint64_t y_lo, uint64_t y_hi, int wrap_y, hipStream_t stream)
 {
     if (y_lo == y_hi) return LBM_OK;
@@ -229,30 +229,14 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
     constexpr int V = vec_width<T>();
     const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, wrap_y);
     const uint64_t rows = y_hi - y_lo;
-    if (g_arith != lbm::kArithUnrolled) {
-        // the other spellings live in the element-wise kernel and in the multi-step kernels
-        const unsigned block = pick_block(nx);
-        const dim3 grid = sweep_grid(nx, block, rows);
-        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
-        if (g_arith == lbm::kArithRolled) {
-            LBM_FOR_BLOCK(block,
-                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithRolled>), grid, dim3(B), 0, stream, f, buf, g,
-                                   0u, (uint32_t)nx, 1, om, (T)0))
-        } else {
-            LBM_FOR_BLOCK(block,
-                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, f, buf, g,
-                                   0u, (uint32_t)nx, 1, om, (T)0))
-        }
-        return launch_status(PULL ? "pull periodic (element-wise)" : "push periodic (element-wise)");
-    }
     if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
         const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         LBM_FOR_BLOCK(block,
-            if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om);
-            else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B>), grid, dim3(B), lds, stream, f, buf, g, om))
+            if (PULL) hipLaunchKernelGGL((lbm::k_pull_periodic_vec<T, V, B, ARITH>), grid, dim3(B), lds, stream, f, buf, g, om);
+            else      hipLaunchKernelGGL((lbm::k_push_periodic_vec<T, V, B, ARITH>), grid, dim3(B), lds, stream, f, buf, g, om))
     } else if (nx >= 4 * V) {
         // rows that are not a whole number of 16-byte vectors: element-aligned vector kernel
         const uint64_t lanes = (nx + V - 1) / V;
@@ -261,16 +245,28 @@ int sweep_periodic_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, do
         const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B>), grid, dim3(B), lds, stream, f, buf, g, om, (T)0))
+            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B, ARITH>), grid, dim3(B), lds, stream, f, buf, g, om, (T)0))
     } else {
         const unsigned block = pick_block(nx);
         const dim3 grid = sweep_grid(nx, block, rows);
         constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, ARITH>), grid, dim3(B), 0, stream, f, buf, g,
                                0u, (uint32_t)nx, 1, om, (T)0))
     }
     return launch_status(PULL ? "pull periodic" : "push periodic");
+}
+
+// every spelling of the relaxation runs the same kernels (vector, element-aligned vector, one node per lane)
+template <typename T, bool PULL>
+int sweep_periodic_rows(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, uint64_t y_lo, uint64_t y_hi,
+                        int wrap_y, hipStream_t stream)
+{
+    switch (g_arith.load()) {
+        case lbm::kArithRolled: return sweep_periodic_rows_as<T, PULL, lbm::kArithRolled>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+        case lbm::kArithContracted: return sweep_periodic_rows_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+        default: return sweep_periodic_rows_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
+    }
 }
 
 template <bool PULL>
@@ -287,35 +283,20 @@ int periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, 
 }
 
 // ---- halo'd 2-D forms --------------------------------------------------------------------
-template <typename T, bool PULL>
-int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, uint64_t LX,
+template <typename T, bool PULL, int ARITH>
+int sweep_inner_as(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, uint64_t LX,
                 uint64_t LY, uint64_t HX, uint64_t HY, hipStream_t stream)
 {
     if (LX >= HX || LY >= HY) return LBM_OK;
     const lbm::Geom g = make_geom(nx, ny, LY, HY, 0);
     constexpr int V = vec_width<T>();
-    if (g_arith != lbm::kArithUnrolled) {
-        const unsigned block = pick_block(HX - LX);
-        const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
-        constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
-        if (g_arith == lbm::kArithRolled) {
-            LBM_FOR_BLOCK(block,
-                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithRolled>), grid, dim3(B), 0, stream, (const T *)f_,
-                                   (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
-        } else {
-            LBM_FOR_BLOCK(block,
-                hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, (const T *)f_,
-                                   (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
-        }
-        return launch_status("periodic inner (element-wise)");
-    }
     if (PULL && HX - LX >= 4 * (uint64_t)V) {
         const uint64_t lanes = (HX - LX + V - 1) / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, HY - LY);
         const size_t lds = residency_ballast(block, sizeof(T), true, nx, ny);
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_pull_inner_vec<T, V, B>), grid, dim3(B), lds, stream, (const T *)f_,
+            hipLaunchKernelGGL((lbm::k_pull_inner_vec<T, V, B, ARITH>), grid, dim3(B), lds, stream, (const T *)f_,
                                (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, (T)om_))
         return launch_status("pull periodic inner");
     }
@@ -323,9 +304,20 @@ int sweep_inner(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const dim3 grid = sweep_grid(HX - LX, block, HY - LY);
     constexpr int MODE = PULL ? lbm::kPullPeriodic : lbm::kPushPeriodic;
     LBM_FOR_BLOCK(block,
-        hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, (const T *)f_,
+        hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, ARITH>), grid, dim3(B), 0, stream, (const T *)f_,
                            (T *)buf_, g, (uint32_t)LX, (uint32_t)HX, 0, (T)om_, (T)0))
     return launch_status("periodic inner");
+}
+
+template <typename T, bool PULL>
+int sweep_inner(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, uint64_t LX, uint64_t LY, uint64_t HX,
+                uint64_t HY, hipStream_t stream)
+{
+    switch (g_arith.load()) {
+        case lbm::kArithRolled: return sweep_inner_as<T, PULL, lbm::kArithRolled>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
+        case lbm::kArithContracted: return sweep_inner_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
+        default: return sweep_inner_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
+    }
 }
 
 template <bool PULL>
@@ -376,8 +368,8 @@ int outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double o
 }
 
 // ---- lid-driven cavity ---------------------------------------------------------------------
-template <typename T, bool PULL>
-int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_,
+template <typename T, bool PULL, int ARITH>
+int sweep_lid_rows_as(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_, double rho_,
                    double u_, uint64_t y_lo, uint64_t y_hi, int64_t y_goff, uint64_t ny_glob,
                    hipStream_t stream)
 {
@@ -391,21 +383,13 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
     constexpr int V = vec_width<T>();
     const lbm::Geom g = make_geom(nx, ny, y_lo, y_hi, 0, y_goff, ny_glob);
     const uint64_t rows = y_hi - y_lo;
-    if (g_arith == lbm::kArithContracted) {
-        // the contracted spelling lives in the element-wise kernel and in the multi-step kernels
-        const unsigned block = pick_block(nx);
-        const dim3 grid = sweep_grid(nx, block, rows);
-        constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
-        LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, lbm::kArithContracted>), grid, dim3(B), 0, stream, f, buf, g,
-                               0u, (uint32_t)nx, 0, om, df))
-    } else if (nx % V == 0 && nx >= 2 * V) {
+    if (nx % V == 0 && nx >= 2 * V) {
         const uint64_t lanes = nx / V;
         const unsigned block = pick_block(lanes);
         const dim3 grid = sweep_grid(lanes, block, rows);
         const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL>), grid, dim3(B), lds, stream, f, buf, g, om, df))
+            hipLaunchKernelGGL((lbm::k_lid_vec<T, V, B, PULL, ARITH>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else if (nx >= 4 * V) {
         const uint64_t lanes = (nx + V - 1) / V;
         const unsigned block = pick_block(lanes);
@@ -413,16 +397,26 @@ int sweep_lid_rows(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double 
         const size_t lds = residency_ballast(block, sizeof(T), PULL, nx, ny);
         constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B>), grid, dim3(B), lds, stream, f, buf, g, om, df))
+            hipLaunchKernelGGL((lbm::k_sweep_vec_any<T, V, MODE, B, ARITH>), grid, dim3(B), lds, stream, f, buf, g, om, df))
     } else {
         const unsigned block = pick_block(nx);
         const dim3 grid = sweep_grid(nx, block, rows);
         constexpr int MODE = PULL ? lbm::kPullLid : lbm::kPushLid;
         LBM_FOR_BLOCK(block,
-            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B>), grid, dim3(B), 0, stream, f, buf, g,
+            hipLaunchKernelGGL((lbm::k_sweep_scalar<T, MODE, B, ARITH>), grid, dim3(B), 0, stream, f, buf, g,
                                0u, (uint32_t)nx, 0, om, df))
     }
     return launch_status(PULL ? "pull lid-driven" : "push lid-driven");
+}
+
+// the cavity sweep has one spelling in the reference and its contraction; the rolled switch does not apply
+template <typename T, bool PULL>
+int sweep_lid_rows(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, double rho, double u, uint64_t y_lo,
+                   uint64_t y_hi, int64_t y_goff, uint64_t ny_glob, hipStream_t stream)
+{
+    if (g_arith == lbm::kArithContracted)
+        return sweep_lid_rows_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, rho, u, y_lo, y_hi, y_goff, ny_glob, stream);
+    return sweep_lid_rows_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, rho, u, y_lo, y_hi, y_goff, ny_glob, stream);
 }
 
 template <bool PULL>
@@ -675,7 +669,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
     // length the fused kernels cannot take
     if (k == 1 && g_layout == LBM_LAYOUT_SOA &&
-        (!supported || (wrap_y && y_lo == 0 && y_hi == ny && g_arith != lbm::kArithContracted)))
+        (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
         return periodic_rows<PULL>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
     if (!wrap_y && y_lo < y_hi && (y_lo < (uint64_t)k || y_hi + (uint64_t)k > ny))
@@ -703,7 +697,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
     {
         const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
         const bool whole = y_lo == 0 && y_hi == ny && y_goff == 0 && ny_glob == ny;
-        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || (whole && g_arith != lbm::kArithContracted)))
+        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || whole))
             return lid_rows<PULL>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
     }
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;

@@ -415,7 +415,7 @@ __device__ __forceinline__ uint32_t row_down(const Geom &g, uint32_t y)
 // first and last lane of a row reach one element outside the row; that element is still inside
 // the array (channels 1,5,8 are never plane 0, channels 3,6,7 never plane 8), its value is
 // replaced afterwards by the periodic neighbour, and only those two lanes take that branch.
-template <typename T, int V, int BLOCK>
+template <typename T, int V, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
@@ -454,7 +454,7 @@ k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         T r[9];
-        collide<T>(c0[i], c1[i], c2[i], c3[i], c4[i], c5[i], c6[i], c7[i], c8[i], om, r);
+        collide<T, ARITH>(c0[i], c1[i], c2[i], c3[i], c4[i], c5[i], c6[i], c7[i], c8[i], om, r);
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
     }
@@ -473,7 +473,7 @@ k_pull_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 //     relaxes the node left of the chunk, the last lane the node right of it (periodic in x), so
 //     a wave writes exactly the lines it owns.  The two halo nodes cost 9 dword loads by two lanes
 //     and one extra pass of the relaxation arithmetic.
-template <typename T, int V, int BLOCK>
+template <typename T, int V, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om)
 {
@@ -508,17 +508,17 @@ k_push_periodic_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, 
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         T r[9];
-        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+        collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
                    c[8][i], om, r);
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
     }
-    if (first || last) collide<T>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
+    if (first || last) collide<T, ARITH>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
     if (first && last) {
         T h2[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) h2[q] = rq[q][hx_right];
-        collide<T>(h2[0], h2[1], h2[2], h2[3], h2[4], h2[5], h2[6], h2[7], h2[8], om, ho2);
+        collide<T, ARITH>(h2[0], h2[1], h2[2], h2[3], h2[4], h2[5], h2[6], h2[7], h2[8], om, ho2);
     }
     // destination vectors at [x0, x0+V): +x movers take their first element from the lane to the
     // left (or the left halo), -x movers their last element from the lane to the right (or the
@@ -665,7 +665,7 @@ __device__ __forceinline__ void lid_pull_node(const T *__restrict__ f, T *__rest
 // each end of the wave's chunk (as k_push_periodic_vec).  Every lane writes exactly the x range it
 // owns: the wall lanes' node-wise scatter skips the one target that belongs to the neighbouring
 // lane's vector and adds the one element per channel that arrives from that neighbour.
-template <typename T, int V, int BLOCK, bool PULL>
+template <typename T, int V, int BLOCK, bool PULL, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
 {
@@ -682,7 +682,7 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const uint32_t x = x0 + i;
-                lid_pull_node<T>(f, buf, plane, g.nx, x, y, x == 0, x == g.nx - 1, t, b, om, df_lid);
+                lid_pull_node<T, (ARITH == kArithRolled ? kArithUnrolled : ARITH)>(f, buf, plane, g.nx, x, y, x == 0, x == g.nx - 1, t, b, om, df_lid);
             }
             return;
         }
@@ -721,7 +721,7 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             T r[9];
-            collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+            collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
                        c[8][i], om, r);
 #pragma unroll
             for (int q = 0; q < 9; ++q) o[q][i] = r[q];
@@ -753,12 +753,12 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         T r[9];
-        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+        collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
                    c[8][i], om, r);
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
     }
-    if (first || last) collide<T>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
+    if (first || last) collide<T, ARITH>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], om, ho);
     // shuffles are executed by every lane of the wave, wall lanes included (their neighbours read
     // from them)
     T d[6][V];
@@ -838,7 +838,7 @@ k_lid_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om
 // MODE as ScalarMode below.
 enum ScalarMode { kPullPeriodic = 0, kPushPeriodic = 1, kPullLid = 2, kPushLid = 3 };
 
-template <typename T, int V, int MODE, int BLOCK>
+template <typename T, int V, int MODE, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const T om, const T df_lid)
 {
@@ -859,14 +859,14 @@ k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, cons
             const uint32_t x = x0 + i;
             if (LID) {
                 const bool l = (x == 0), r = (x == g.nx - 1);
-                if (PULL) lid_pull_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
-                else      lid_push_node<T>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+                if (PULL) lid_pull_node<T, (ARITH == kArithRolled ? kArithUnrolled : ARITH)>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
+                else      lid_push_node<T, (ARITH == kArithRolled ? kArithUnrolled : ARITH)>(f, buf, plane, g.nx, x, y, l, r, t, b, om, df_lid);
             } else {
                 const uint32_t xr = (x + 1 == g.nx) ? 0u : x + 1;
                 const uint32_t xl = (x == 0) ? g.nx - 1 : x - 1;
                 const uint32_t yu = row_up(g, y), yd = row_down(g, y);
-                if (PULL) pull_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
-                else      push_node<T>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+                if (PULL) pull_node<T, ARITH>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
+                else      push_node<T, ARITH>(f, buf, plane, g.nx, x, y, xl, xr, yd, yu, om);
             }
         }
         return;
@@ -892,7 +892,7 @@ k_sweep_vec_any(const T *__restrict__ f, T *__restrict__ buf, const Geom g, cons
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         T r[9];
-        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
+        collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i],
                    c[8][i], om, r);
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
@@ -985,7 +985,7 @@ k_outer_ring(const T *__restrict__ f, T *__restrict__ buf, uint32_t nx, uint32_t
 // with a halo): no node of the rectangle touches the array edge, so nothing wraps.  A lane takes V
 // nodes from LX + lane * V with element-aligned 128-bit accesses; the lane that would cross HX goes
 // node by node.  2.2 x the element-wise kernel at 16384^2 fp32.
-template <typename T, int V, int BLOCK>
+template <typename T, int V, int BLOCK, int ARITH = kArithUnrolled>
 __global__ void __launch_bounds__(BLOCK)
 k_pull_inner_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, const uint32_t LX, const uint32_t HX,
                  const T om)
@@ -997,7 +997,7 @@ k_pull_inner_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, con
     const size_t plane = (size_t)g.ny * g.nx;
     const uint32_t yu = y + 1, yd = y - 1;
     if (x0 + V > HX) {
-        for (uint32_t x = x0; x < HX; ++x) pull_node<T>(f, buf, plane, g.nx, x, y, x - 1, x + 1, yd, yu, om);
+        for (uint32_t x = x0; x < HX; ++x) pull_node<T, ARITH>(f, buf, plane, g.nx, x, y, x - 1, x + 1, yd, yu, om);
         return;
     }
     T c[9][V];
@@ -1014,7 +1014,7 @@ k_pull_inner_vec(const T *__restrict__ f, T *__restrict__ buf, const Geom g, con
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         T r[9];
-        collide<T>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
+        collide<T, ARITH>(c[0][i], c[1][i], c[2][i], c[3][i], c[4][i], c[5][i], c[6][i], c[7][i], c[8][i], om, r);
 #pragma unroll
         for (int q = 0; q < 9; ++q) o[q][i] = r[q];
     }

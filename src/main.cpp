@@ -418,6 +418,16 @@ int main(int argc, char *argv[])
     die_hip(hipSetDevice(0), "hipSetDevice");
     die_hip(hipFree(nullptr), "HIP runtime start-up");
     die_hip(hipStreamCreate(&r.stream), "stream");
+    {
+        // the device code is loaded at the first launch: one one-element kernel of the library here, still
+        // on the start-up side of the clock
+        void *probe = nullptr;
+        die_hip(hipMalloc(&probe, 256), "start-up probe");
+        die_hip(hipMemset(probe, 0x3f, 256), "start-up probe");
+        die_lbm(lbm_selftest_reciprocal(probe, (char *)probe + 128, kPrec, 1, r.stream), "start-up probe");
+        die_hip(hipStreamSynchronize(r.stream), "start-up probe");
+        (void)hipFree(probe);
+    }
 
     // How many y-slabs: -gpus N, else LBM_GPUS=N; a build with USE_MPI set (the reference's multi-rank
     // build, macros.h:8, started there as `mpirun -n N ./main`) takes every visible device.  One slab
