@@ -591,11 +591,30 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const uint64_t nsegs_grid = g.xcd_map ? (nsegs + 7) / 8 * 8 : nsegs;
     const uint64_t nwall = nstrips < 2 ? nstrips : 2;
     const uint64_t blocks = nsegs_wall ? (nstrips - nwall) * nsegs + nwall * nsegs_wall : nstrips * nsegs_grid;
-    const dim3 grid((unsigned)blocks), block(lbm::kWave);
+    // Wavefronts per workgroup (lbm::fused_group_waves): groups on lattices of many rounds, where
+    // neighbouring strips that start together share their common lines in the cache; single
+    // wavefronts, free to go to any compute unit, on small ones.  A group's LDS can exceed the
+    // 64 KiB a kernel may ask for without saying so beforehand.
+    const bool grouped = !small_grid && nsegs_wall == 0 && !g.xcd_map;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesForProps) dev = 0;
 #define LBM_FUSED_CASE(KK)                                                                                       \
-    case KK:                                                                                                     \
-        hipLaunchKernelGGL((lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>), grid, block, 0, stream, f, buf, g, om, df); \
-        break;
+    case KK: {                                                                                                   \
+        const unsigned nw = grouped ? (unsigned)lbm::fused_group_waves<T, V, KK, PUSH, LID, AOS, ARITH>() : 1u;  \
+        const unsigned lds = nw * (unsigned)lbm::fused_lds_bytes_per_wave<T, V, KK, PUSH, LID, AOS, ARITH>();    \
+        auto kern = lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>;                                               \
+        static std::atomic<bool> lds_allowed[kMaxDevicesForProps];                                               \
+        if (lds > 64 * 1024 && !lds_allowed[dev].load()) {                                                       \
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                     (int)lds);                                                  \
+            if (e != hipSuccess)                                                                                 \
+                return fail(LBM_ERR_HIP, "hipFuncSetAttribute(%u bytes of LDS): %s", lds, hipGetErrorString(e)); \
+            lds_allowed[dev].store(true);                                                                        \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((blocks + nw - 1) / nw)), dim3(lbm::kWave * nw), lds, stream,   \
+                           f, buf, g, om, df);                                                                   \
+        break;                                                                                                   \
+    }
     switch (k) {
         LBM_FUSED_CASE(1)
         LBM_FUSED_CASE(2)

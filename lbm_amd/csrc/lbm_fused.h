@@ -7,6 +7,8 @@
 //
 //   * one wavefront owns a strip of 64 x 8 bytes of a row and marches it through a segment of
 //     rows; one row of 9 x 512 bytes is loaded per iteration (prefetched one iteration ahead).
+//     On large lattices four wavefronts with adjacent strips form a workgroup (fused_group_waves):
+//     they share nothing but the cache lines their windows have in common;
 //     Eight bytes per lane, not sixteen: a lone wavefront per SIMD cannot hide its own issue and
 //     memory stalls (measured 62 % VALU-active at K=4 with 16-byte lanes and 440 VGPRs); with half
 //     the nodes per lane the K=4 pull kernel fits 256 VGPRs, two wavefronts share a SIMD and the
@@ -67,6 +69,10 @@
 #ifndef LBM_FUSED_PREFETCH_F32
 #define LBM_FUSED_PREFETCH_F32 1
 #endif
+// Wavefronts per workgroup (0 = the built-in choice, fused_group_waves()).
+#ifndef LBM_FUSED_GROUP_WAVES
+#define LBM_FUSED_GROUP_WAVES 0
+#endif
 
 namespace lbm {
 
@@ -101,6 +107,39 @@ constexpr int fused_reg_rings()
     if (LID) return PUSH ? 3 : 2;      // pull cavity kernels spill with three from six steps on
     return 4;
 }
+
+// Streaming steps done in registers or LDS (everything but the step that reads memory).
+template <int K, bool PUSH, bool AOS> constexpr int fused_ring_steps() { return (PUSH || AOS) ? K : K - 1; }
+
+// LDS of one wavefront: the rings that do not live in registers (4.5 KiB each).
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_lds_bytes_per_wave()
+{
+    constexpr int rings = fused_ring_steps<K, PUSH, AOS>() - fused_reg_rings<T, V, PUSH, LID, AOS, ARITH>();
+    return (rings > 0 ? rings : 0) * 9 * kWave * V * (int)sizeof(T);
+}
+
+// Wavefronts per workgroup: a launch-time choice, 1 .. kFusedMaxGroupWaves (blockDim.x = 64 x that,
+// dynamic LDS = fused_lds_bytes_per_wave() x that).  The wavefronts of a group take adjacent strips
+// and share nothing but the cache: they start together on one compute unit, so the 128-byte lines
+// that the 512-byte windows of neighbouring strips have in common are fetched once instead of once
+// per strip (strips dealt one per workgroup land on different XCDs, each with an L2 of its own).
+// fused_group_waves() is the choice for lattices of many rounds of wavefronts: four where two groups
+// still fit the LDS of a compute unit (two wavefronts per SIMD), else one.  16384^2, groups of four
+// against single wavefronts: fp64 seven steps (384-byte strips share two lines of five with either
+// neighbour) 18 % fewer bytes fetched, 172 -> 180 GLUPS; fp32 eight steps 18 % fewer bytes fetched,
+// 443 -> 447 GLUPS.  Small lattices keep one wavefront per workgroup, free to go to any compute unit.
+constexpr int kFusedMaxGroupWaves = LBM_FUSED_GROUP_WAVES > 4 ? LBM_FUSED_GROUP_WAVES : 4;
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_group_waves()
+{
+    if (LBM_FUSED_GROUP_WAVES > 0) return LBM_FUSED_GROUP_WAVES;
+    if (AOS) return 1;
+    return 8 * fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>() <= 160 * 1024 ? kFusedMaxGroupWaves : 1;
+}
+
+// The LDS of a workgroup, carved up by fused_body.
+extern __shared__ __align__(16) unsigned char fused_lds_raw[];
 
 struct FusedGeom {
     uint32_t nx, ny;        // row length, rows in the array
@@ -322,7 +361,7 @@ struct RowIn {
     T w[2];         // lid pull, outermost strips: the row's own 6 at x = 0 and own 5 at x = nx-1
 };
 
-// K time steps of one scene/scheme.  grid.x = nstrips * nsegs workgroups of one wavefront.
+// K time steps of one scene/scheme.  nstrips * nsegs wavefronts, in workgroups of blockDim.x / 64.
 // AOS: the arrays are [NY][NX][9].  The pull scheme then reads each row's own nine (post-collision)
 // populations like the push scheme does and streams every step in registers, the first one included.
 // ARITH: spelling of the relaxation (lbm_device.h).  kArithRolled is the reference's UNROLL_LOOPS=false
@@ -337,41 +376,46 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
     constexpr bool OWN = PUSH || AOS;        // a row is loaded as its own nine populations
-    constexpr int NG = OWN ? K : K - 1;      // streaming steps done in registers
+    constexpr int NG = fused_ring_steps<K, PUSH, AOS>();   // streaming steps done in registers or LDS
     constexpr int D = NG;                    // rows between a segment's first row and the first row relaxed
     constexpr int NR = NG > 0 ? NG : 1;
 
-    // Workgroups go to the 8 XCDs round-robin.  Plain mapping: strip fastest, so the two neighbours
-    // of a strip (which share its halo lines) run on other XCDs.  xcd_map: XCD j takes segments
-    // j, j+8, ... and walks all strips of a segment in order, so halo lines are shared in one L2.
-    // Measured at 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every
-    // segment's strips instead): address-order dispatch is worth more than the shared lines.
+    // A workgroup of several wavefronts stands for as many consecutive single-wavefront blocks; the
+    // wavefront's index is read into a scalar register, since row addresses must stay wave-uniform.
+    // Blocks are numbered strip fastest, and workgroups go to the 8 XCDs round-robin: the strips of
+    // one group share their common lines in one L2, the neighbours across a group boundary do not.
+    // xcd_map (single wavefronts only): XCD j takes segments j, j+8, ... and walks all strips of a
+    // segment in order, so every shared line meets its second reader in the same L2.  Measured at
+    // 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every segment's strips
+    // instead): address-order dispatch is worth more than the shared lines.
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t block = blockIdx.x * (blockDim.x / kWave) + wave;
     uint32_t strip, seg, seg_rows = g.seg_rows, nsegs = g.nsegs;
     if (LID && g.nsegs_wall != 0) {
         // first the wall strips with their own (shorter) segments -- the slowest wavefronts start
         // first --, then the strips without walls, segment by segment
         const uint32_t nwall = g.nstrips < 2 ? g.nstrips : 2u, nmid = g.nstrips - nwall;
         const uint32_t wall_blocks = nwall * g.nsegs_wall;
-        if (blockIdx.x < wall_blocks) {
-            strip = (blockIdx.x % nwall) ? g.nstrips - 1 : 0u;
-            seg = blockIdx.x / nwall;
+        if (block < wall_blocks) {
+            strip = (block % nwall) ? g.nstrips - 1 : 0u;
+            seg = block / nwall;
             seg_rows = g.seg_rows_wall;
             nsegs = g.nsegs_wall;
         } else {
-            const uint32_t b = blockIdx.x - wall_blocks;
+            const uint32_t b = block - wall_blocks;
             strip = 1 + b % nmid;
             seg = b / nmid;
         }
     } else if (g.xcd_map) {
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t xcd = block & 7u, slot = block >> 3;
         seg = (slot / g.nstrips) * 8 + xcd;
         strip = slot % g.nstrips;
     } else {
-        strip = blockIdx.x % g.nstrips;
-        seg = blockIdx.x / g.nstrips;
+        strip = block % g.nstrips;
+        seg = block / g.nstrips;
     }
     if (seg >= nsegs) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x % kWave;
     const uint32_t nxv = g.nx / V;
     int64_t vx = (int64_t)strip * W - H + (int64_t)lane;
     if (LID) {
@@ -469,7 +513,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     constexpr int NLDS = NG > kRegRings ? NG - kRegRings : 0;
     constexpr int NREG = NG - NLDS > 0 ? NG - NLDS : 1;
     typedef typename VecTypes<T, V>::vec_t ring_vec_t;
-    __shared__ ring_vec_t ring_lds[NLDS > 0 ? NLDS : 1][9][kWave];   // [ring][set*3 + k | 6 + k][lane]
+    // this wavefront's part of the workgroup's LDS: [ring][set*3 + k | 6 + k][lane]
+    ring_vec_t (*ring_lds)[9][kWave] = reinterpret_cast<ring_vec_t (*)[9][kWave]>(
+        fused_lds_raw + wave * (uint32_t)fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>());
     T ringA[NREG][3][V], ringB[NREG][3][V], ringC[NREG][3][V], ring7[NR], ring8[NR];
 #pragma unroll
     for (int s = 0; s < NREG; ++s) {
@@ -481,7 +527,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 #pragma unroll
     for (int s = 0; s < NR; ++s) { ring7[s] = T(1); ring8[s] = T(1); }
     auto lds_get = [&](T (&d)[V], int ring, uint32_t slot) {
-        const ring_vec_t v = ring_lds[ring][slot][threadIdx.x];
+        const ring_vec_t v = ring_lds[ring][slot][lane];
 #pragma unroll
         for (int e = 0; e < V; ++e) d[e] = v[e];
     };
@@ -489,7 +535,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
         ring_vec_t v;
 #pragma unroll
         for (int e = 0; e < V; ++e) v[e] = d[e];
-        ring_lds[ring][slot][threadIdx.x] = v;
+        ring_lds[ring][slot][lane] = v;
     };
 
     // Lid scenes, pull, wavefronts of the two outermost strips: the side walls reflect the wall nodes'
@@ -685,7 +731,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 // scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
 // every instantiation fits without spilling (at most 239 VGPRs).
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled>
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");

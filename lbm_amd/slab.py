@@ -9,10 +9,11 @@ pair is already contiguous, so the three populations that cross a slab edge are 
 main.cpp:238-273, :339-374).
 
 Two schedules share this layout.  Lattices that stream from HBM (and whose rows are whole 16-byte
-vectors) run the deep-halo schedule: G = 6 ghost rows per side hold plain copies of the neighbour's
+vectors) run the deep-halo schedule: G ghost rows per side (the steps one launch takes: 7 or 8
+on large slabs) hold plain copies of the neighbour's
 edge rows, a block of up to G time steps is advanced by one fused launch per region (see
 csrc/lbm_fused.h: every population crosses HBM once per block, not once per step), and ghost rows
-are refreshed once per block -- nine contiguous G-row messages per direction.  Everything else
+are refreshed once per block -- one message of nine G-row blocks per direction.  Everything else
 runs the one-row schedule described next.  In both, the interior and the edge regions of a slab
 are advanced on two streams so that the exchange hides behind the interior update.
 
@@ -103,10 +104,15 @@ _EDGE_STREAMS = {}
 def _edge_stream(device: torch.device) -> "torch.cuda.Stream":
     """The one edge/communication stream of a device, shared by every slab on it.
 
-    Created once per process and device: which hardware queue a HIP stream lands on depends on how
-    many streams were created before it, and with RCCL's own streams in the same few queues a
-    process that kept taking fresh high-priority streams (one per slab object) was seen to stall on
-    its fourth.  Slabs that share the stream are simply ordered behind each other on it.
+    Created once per process and device.  Each new high-priority stream makes the HIP runtime open
+    one more high-priority hardware queue on first use, up to GPU_MAX_HW_QUEUES (4 by default), and
+    on this platform the device was seen to stop draining exactly when a process's last permitted
+    high-priority queue starts taking cross-stream event waits (fourth stream by default, third
+    with the limit at 3, never with the limit at 2 or with default-priority streams): a 40-line
+    torch-only program with the same stream and event pattern reproduces it, with local copies in
+    place of RCCL and no kernel of this package.  The schedule's event graph is acyclic (every wait
+    names an event recorded earlier in host order), so slab objects share one high-priority queue
+    instead of taking a stream each; slabs that share it are ordered behind each other on it.
     """
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     s = _EDGE_STREAMS.get(key)
@@ -328,9 +334,11 @@ class SlabSimulation:
     def _transfer(self, items) -> None:
         """One grouped send/recv; items are ("send" | "recv", tensor, group rank of the peer, tag)
         in posting order.  A transport that is not stream-ordered (gloo, the rehearsal transport)
-        gets host tensors: what it does with device pointers is its own business, and receives that
-        land in device memory behind the GPU's caches were seen to leave a later kernel with stale
-        values now and then."""
+        gets host tensors.  Handed device tensors, gloo writes the received bytes into device
+        memory with host stores through the PCIe aperture; nothing orders those stores against a
+        kernel launched afterwards (the request completes when the host has issued them, not when
+        they have landed), and a later sweep now and then read a few thousand stale values.  A
+        staged receive ends in an ordinary host-to-device copy on the stream instead."""
         if not items:
             return
         staged = self.cuda and not self.stream_ordered

@@ -47,11 +47,14 @@ void add(std::vector<Variant> &vs, uint32_t nx, uint32_t ny, T om, uint32_t seg_
 {
     constexpr int W = 64 - 2 * fused_halo_lanes<T, V, K>();
     FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0, 0, 0, 0};
+    constexpr unsigned NW = (unsigned)fused_group_waves<T, V, K, TK_PUSH, false, false, TK_ARITH>();
+    constexpr unsigned lds = NW * (unsigned)fused_lds_bytes_per_wave<T, V, K, TK_PUSH, false, false, TK_ARITH>();
+    const dim3 grid((g.nstrips * g.nsegs + NW - 1) / NW);
     auto kern = k_fused<T, V, K, TK_PUSH, false, false, TK_ARITH>;
-    const dim3 grid(g.nstrips * g.nsegs);
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     char nm[96];
     snprintf(nm, sizeof nm, "K%d_S%u", K, seg_rows);
-    vs.push_back({nm, K, [=](const T *a, T *b) { hipLaunchKernelGGL(kern, grid, dim3(64), 0, 0, a, b, g, om, (T)0); }, {}});
+    vs.push_back({nm, K, [=](const T *a, T *b) { hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, 0, a, b, g, om, (T)0); }, {}});
 }
 
 // segment length in 96..128 that minimises rounds x iterations (as the library does)
@@ -74,6 +77,7 @@ int main(int argc, char **argv)
     uint32_t nx = 16384, ny = 16384; int rounds = 3, iters = 6;
     if (argc > 1) nx = atoi(argv[1]);
     if (argc > 2) ny = atoi(argv[2]);
+    if (getenv("TK_ITERS")) iters = atoi(getenv("TK_ITERS"));     // launches per timed burst
     const size_t n = (size_t)9 * nx * ny;
     T *a, *b, *c, *d;
     CK(hipMalloc(&a, n * sizeof(T))); CK(hipMalloc(&b, n * sizeof(T)));
