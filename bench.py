@@ -258,7 +258,7 @@ def main():
         out, kmax = [], (sim.G if hasattr(sim, "G") else None)
         while n > 0:
             if kmax is None:
-                k = ops.plan_steps(sim.f, probe_rows, n)
+                k = ops.plan_steps(sim.f, probe_rows, n, lid=args.scene == "lid")
             else:
                 k = -(-n // -(-n // kmax))
             out.append(k)
@@ -327,7 +327,7 @@ def main():
         sim2 = Simulation(nx, ny_loc, scene=args.scene, scheme=args.scheme, dtype=dtype, omega=args.omega, device=device)
         plan2, n = [], args.steps
         while n > 0:
-            plan2.append(ops.plan_steps(sim2.f, ny_loc, n))
+            plan2.append(ops.plan_steps(sim2.f, ny_loc, n, lid=args.scene == "lid"))
             n -= plan2[-1]
         sim2.step(args.warmup)
         for k in sorted(set(plan2) - set(sim2.launch_steps)):

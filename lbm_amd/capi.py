@@ -44,6 +44,7 @@ SIGNATURES = {
     "lbm_pull_lid_rows": (_int, [_ptr, _ptr, _int, _u64, _u64, _dbl, _dbl, _dbl, _u64, _u64, _i64, _u64, _ptr]),
     "lbm_fused_max_steps": (_int, [_int, _u64]),
     "lbm_plan_steps": (_int, [_int, _u64, _u64, _u64]),
+    "lbm_plan_steps_scene": (_int, [_int, _u64, _u64, _u64, _int]),
     "lbm_pull_periodic_fused": (_int, [_ptr, _ptr, _int, _u64, _u64, _dbl, _u64, _u64, _int, _int, _ptr]),
     "lbm_push_periodic_fused": (_int, [_ptr, _ptr, _int, _u64, _u64, _dbl, _u64, _u64, _int, _int, _ptr]),
     "lbm_push_lid_fused": (_int, [_ptr, _ptr, _int, _u64, _u64, _dbl, _dbl, _dbl, _u64, _u64, _i64, _u64, _int, _ptr]),

@@ -72,7 +72,7 @@ constexpr unsigned kWavesPerCU_f32 = 6;       // top of the plateau for fp32 pul
 constexpr unsigned kWavesPerCU_f64_pull = 5;  // fp64 pull: 4 is best by 1 % but sits on the cliff to 3
 constexpr unsigned kWavesPerCU_f64_push = 6;
 constexpr unsigned kWavesPerCU_cache_resident = 16;  // fp64 push (aligned-store form): 6 beats 5 by 4 %
-constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr size_t kLdsPerCU = 160 * 1024;   // gfx950, in every partition mode (partitions have fewer units, not smaller ones)
 constexpr size_t kMaxDynamicLds = 64 * 1024;
 
 // Re-deal workgroups so that one XCD walks whole rows (lbm::block_coords).  Off by default:
@@ -564,8 +564,12 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     // the wall cases in every iteration, about a fifth slower than the others (1024^2 fp32, four
     // steps: 44 against 36 us per launch), and a small grid is over when its slowest wavefront is.
     // They get segments short enough to finish with everyone else.
+    // LBM_FUSED_GROUP (read at every launch; tests and tuning): 0 = one wavefront per workgroup
+    // everywhere, 1 = groups wherever the kernel's rings allow them, whatever the lattice size
+    const char *group_env = getenv("LBM_FUSED_GROUP");
+    const int group_mode = group_env ? atoi(group_env) : -1;
     uint64_t seg_wall = 0, nsegs_wall = 0;
-    if (LID && small_grid && !g_fused_xcd && g_fused_wall_split) {
+    if (LID && small_grid && !g_fused_xcd && g_fused_wall_split && group_mode <= 0) {
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
         const uint64_t iters = (seg + extra) * 5 / 6;          // iterations at 1.2 x the time each
         const uint64_t slots = wave_slots(), nwall = nstrips < 2 ? nstrips : 2;
@@ -595,7 +599,7 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     // neighbouring strips that start together share their common lines in the cache; single
     // wavefronts, free to go to any compute unit, on small ones.  A group's LDS can exceed the
     // 64 KiB a kernel may ask for without saying so beforehand.
-    const bool grouped = !small_grid && nsegs_wall == 0 && !g.xcd_map;
+    const bool grouped = nsegs_wall == 0 && !g.xcd_map && (group_mode < 0 ? !small_grid : group_mode > 0);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesForProps) dev = 0;
 #define LBM_FUSED_CASE(KK)                                                                                       \
@@ -1098,6 +1102,10 @@ int lbm_fused_max_steps(int prec, uint64_t nx)
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
 {
+    return lbm_plan_steps_scene(prec, nx, rows, remaining, 0);
+}
+int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remaining, int lid)
+{
     if (remaining == 0) return 0;
     const int kmax = lbm_fused_max_steps(prec, nx);
     if (kmax <= 1) return kmax;   // 0: bad precision, 1: one-step sweeps only
@@ -1111,9 +1119,11 @@ int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
     // Large lattices (16384^2, GLUPS at 6/7/8 steps): fp32 strict 325/334/335, contracted 377/410/424
     // (push 372/401/411); fp64 contracted pull 162/167/171, push 159/166/162.  The strict and rolled
     // spellings and the fp64 sweeps take seven (an eighth step gains little or nothing and deepens
-    // the halos of a decomposed run), contracted fp32 eight.
+    // the halos of a decomposed run), contracted fp32 eight -- seven in the cavity, whose kernels
+    // keep the wall cases in registers and one ring more in LDS (seven steps 397 / 399 GLUPS pull /
+    // push, eight 394 / 380).
     uint64_t dflt = (uint64_t)kmax;
-    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
+    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64 || lid)) dflt = 7;
     // Small lattices (one round of wavefronts or less) are bound by the chain of dependent iterations
     // of a wavefront; more steps lengthen the chain.  fp32 pull, GLUPS at 3/4/5/6/7/8 steps: 512^2
     // 50/56/57/53/52/49, 1024^2 107/128/144/137/136/133, 1536^2 135/160/197/203/212/213, 2048^2

@@ -246,10 +246,11 @@ def fused_max_steps(f) -> int:
     return int(capi.load().lbm_fused_max_steps(_prec(f), nx))
 
 
-def plan_steps(f, rows, remaining) -> int:
-    """Steps the next launch of the time loop should take (1 .. fused_max_steps, <= remaining)."""
+def plan_steps(f, rows, remaining, lid: bool = False) -> int:
+    """Steps the next launch of the time loop should take (1 .. fused_max_steps, <= remaining);
+    lid: the launch is a lid-driven cavity sweep."""
     nx, _ = _check_f(f)
-    return int(capi.load().lbm_plan_steps(_prec(f), nx, int(rows), int(remaining)))
+    return int(capi.load().lbm_plan_steps_scene(_prec(f), nx, int(rows), int(remaining), 1 if lid else 0))
 
 
 def pull_periodic_fused(f, buf, om, y_lo, y_hi, wrap_y, nsteps):

@@ -73,7 +73,7 @@ class Simulation:
     def step(self, n: int = 1, max_fuse: Optional[int] = None) -> None:
         n = int(n)
         while n > 0:
-            k = ops.plan_steps(self.f, self.ny, n)
+            k = ops.plan_steps(self.f, self.ny, n, lid=self.scene == LID_DRIVEN)
             if max_fuse is not None:
                 k = max(1, min(k, int(max_fuse)))
             if k == 1:

@@ -65,8 +65,8 @@ class HipBackend:
     def init_shearwave(self, f, rho, u, y_below, y_glob, halo=1):
         self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=halo)
 
-    def plan_steps(self, f, rows, remaining):
-        return self.ops.plan_steps(f, rows, remaining)
+    def plan_steps(self, f, rows, remaining, lid=False):
+        return self.ops.plan_steps(f, rows, remaining, lid=lid)
 
     def periodic_fused(self, scheme, f, buf, om, y_lo, y_hi, k):
         fn = self.ops.pull_periodic_fused if scheme == "pull" else self.ops.push_periodic_fused
@@ -169,7 +169,7 @@ class SlabSimulation:
         if halo is None:
             probe = torch.empty((9, 1, self.nx), dtype=dtype, device=self.device)
             n_min = self.ny_glob // self.world
-            halo = int(backend.plan_steps(probe, n_min, 1 << 30)) if hasattr(backend, "plan_steps") else 1
+            halo = int(backend.plan_steps(probe, n_min, 1 << 30, scene == LID_DRIVEN)) if hasattr(backend, "plan_steps") else 1
             if n_min < 2 * halo:
                 halo = 1
         self.G = G = int(halo)

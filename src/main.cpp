@@ -338,7 +338,7 @@ static bool run_simulation(Run &r)
 
     const auto t0 = std::chrono::high_resolution_clock::now();
     // The reference's loop body is {output if due, one sweep, swap}.  Between two outputs the
-    // iterations are handed to the library in runs of up to lbm_plan_steps(): same populations,
+    // iterations are handed to the library in runs of up to lbm_plan_steps_scene(): same populations,
     // fewer passes over memory.
     bool pending = false;      // a fetched sample waits to be printed
     unsigned queued = 0;       // launches handed to the device since the sample was fetched
@@ -354,7 +354,7 @@ static bool run_simulation(Run &r)
             const UINT next_out = (t / o.out_every + 1) * o.out_every;
             if (next_out < until) until = next_out;
         }
-        const int k = lbm_plan_steps(kPrec, o.nx, o.ny, until - t);
+        const int k = lbm_plan_steps_scene(kPrec, o.nx, o.ny, until - t, o.scene == LID_DRIVEN);
         if (k < 1) die_lbm(LBM_ERR_INVALID_ARGUMENT, "planning the next sweep");
         int s;
         if (o.scene == LID_DRIVEN) {

@@ -182,7 +182,7 @@ static bool run_simulation_slabs(Run &r, unsigned nslabs)
     const UINT base = o.ny / nslabs, rem = o.ny % nslabs;
     // ghost depth = steps per block: what the library plans for a slab of the smallest height, as long
     // as a slab holds two edge regions of that depth
-    int g = lbm_plan_steps(kPrec, o.nx, base, (uint64_t)1 << 30);
+    int g = lbm_plan_steps_scene(kPrec, o.nx, base, (uint64_t)1 << 30, o.scene == LID_DRIVEN);
     if (g < 1) die_lbm(LBM_ERR_INVALID_ARGUMENT, "planning the slab blocks");
     while (g > 1 && base < 2 * (UINT)g) --g;
     sr.G = (UINT)g;

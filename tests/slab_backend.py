@@ -17,7 +17,7 @@ class OracleBackend:
         orc.init_shearwave(interior, t(rho), t(u), y_below, y_glob)
         a[:, halo:a.shape[1] - halo] = interior
 
-    def plan_steps(self, f, rows, remaining):
+    def plan_steps(self, f, rows, remaining, lid=False):
         return min(self.fused_depth, remaining)
 
     # k steps of rows [y_lo, y_hi) from an array with >= k ghost rows: step j advances rows

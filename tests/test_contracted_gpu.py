@@ -165,6 +165,8 @@ def test_limits():
     big = torch.zeros((9, 4096, 4096), dtype=torch.float32, device="cuda")
     assert ops.plan_steps(big, 4096, 100) <= 8
     assert ops.plan_steps(big, 4096, 20) == 7 and ops.plan_steps(big, 4096, 13) == 7 and ops.plan_steps(big, 4096, 6) == 6
+    # contracted fp32: eight steps in the periodic sweeps, seven in the cavity
+    assert ops.plan_steps(big, 4096, 800) == 8 and ops.plan_steps(big, 4096, 800, lid=True) == 7
     with ops.arithmetic("unrolled"):
         assert ops.plan_steps(big, 4096, 20) == 7 and ops.plan_steps(big, 4096, 500) == 7
         assert ops.plan_steps(big, 4096, 9) == 5 and ops.plan_steps(big, 4096, 3) == 3
@@ -189,17 +191,20 @@ def test_whole_runs_stay_inside_the_parity_budget_of_the_strict_spelling(scene, 
     assert sim.max_velocity() == float(orc.max_velocity(want))
 
 
-def test_full_size_shear_wave_equals_narrow_oracle():
-    """16384 x 16384 fp32, 16 steps in launches of eight: every column against the contracted
-    oracle's 8-column run."""
+@pytest.mark.parametrize("tdt,ndt,scheme", [(torch.float32, np.float32, "pull"), (torch.float32, np.float32, "push"),
+                                            (torch.float64, np.float64, "pull"), (torch.float64, np.float64, "push")])
+def test_full_size_shear_wave_equals_narrow_oracle(tdt, ndt, scheme):
+    """16384 x 16384, 21 steps in launches of seven or eight (workgroups of four wavefronts where
+    their rings fit): every column against the contracted oracle's 8-column run."""
     from lbm_amd import Simulation
     nx = ny = 16384
-    sim = Simulation(nx, ny, scene="shear", scheme="pull", dtype=torch.float32, omega=0.5)
-    sim.step(16)
-    assert sum(sim.launch_steps) == 16 and max(sim.launch_steps) > 6
-    want, _ = orc.run("shear", "pull", 8, ny, 16, 0.5, np.float32)
+    sim = Simulation(nx, ny, scene="shear", scheme=scheme, dtype=tdt, omega=0.5)
+    sim.step(21)
+    assert sum(sim.launch_steps) == 21 and max(sim.launch_steps) > 6
+    want, _ = orc.run("shear", scheme, 8, ny, 21, 0.5, ndt)
     col = torch.from_numpy(np.ascontiguousarray(want[:, :, :1])).cuda()
-    assert bool((sim.f.view(torch.int32) == col.view(torch.int32)).all())
+    bits = torch.int32 if tdt == torch.float32 else torch.int64
+    assert all(bool((sim.f[q].view(bits) == col[q].view(bits)).all()) for q in range(9))
     del sim
     torch.cuda.empty_cache()
 

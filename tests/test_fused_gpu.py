@@ -168,3 +168,32 @@ def test_extreme_aspect_ratios_fused_equals_one_step(dtype):
                         getattr(ops, f"{scheme}_lid_fused")(f, got, 1.2, 1.0, 0.1, 0, ny, 0, ny, k)
                     bits = torch.int32 if dtype == torch.float32 else torch.int64
                     assert bool((got.view(bits) == a.view(bits)).all()), (scene, scheme, nx, ny, k)
+
+
+@pytest.fixture
+def grouped_launches(monkeypatch):
+    """Workgroups of several wavefronts on lattices of any size (the library reads the variable at
+    every launch); without it only lattices of many rounds of wavefronts are launched that way."""
+    monkeypatch.setenv("LBM_FUSED_GROUP", "1")
+    yield
+    monkeypatch.delenv("LBM_FUSED_GROUP", raising=False)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,scheme", list(ONE_STEP))
+@pytest.mark.parametrize("k", [2, 4, 5, 7, 8])
+@pytest.mark.parametrize("arith", ["unrolled", "contracted"])
+def test_workgroups_of_several_wavefronts(grouped_launches, dtype, scene, scheme, k, arith):
+    """The launch form of large lattices -- four adjacent strips per workgroup, rings in dynamic LDS
+    -- on small and ragged ones: strips that do not fill their last group, one strip only, several
+    segments, walls inside a group."""
+    from lbm_amd import ops
+    rng = np.random.default_rng(11 * k + (dtype == np.float64))
+    with ops.arithmetic(arith), orc.arithmetic(arith):
+        for nx, ny in [(64, 48), (1024, 70), (724, 33), (2048, 5), (1536, 300), (8, 3)]:
+            f = random_state(rng, nx, ny, dtype)
+            want = oracle_steps(ONE_STEP[(scene, scheme)], f, k, 0.9, dtype)
+            d_f = torch.from_numpy(f).cuda()
+            d_b = torch.full_like(d_f, float("nan"))
+            run_fused(scene, scheme, d_f, d_b, 0.9, 0, ny, k, ny_glob=ny)
+            assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {arith} {nx}x{ny} k={k} grouped")
