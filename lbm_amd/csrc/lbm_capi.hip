@@ -88,6 +88,9 @@ int xcd_rows_default()
 int g_xcd_rows = xcd_rows_default();
 
 constexpr int kMaxDevicesForProps = 64;
+// lattices below this many nodes (1.5 M) are bound by the chain of dependent iterations of a
+// wavefront, not by memory: five steps per launch (lbm_plan_steps), narrow halos (launch_fused)
+constexpr uint64_t kSmallLatticeNodes = 3ull << 19;
 constexpr uint64_t kMaxExtent = 0x7fffffffull;  // extents are 32-bit inside the kernels
 
 int check_common(const void *f, int prec, uint64_t nx, uint64_t ny)
@@ -510,8 +513,22 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     // rows are addressed through buffer descriptors with 32-bit byte offsets
     if (nx * sizeof(T) >= (uint64_t)lbm::kNoStore)
         return fail(LBM_ERR_UNSUPPORTED, "rows of %llu nodes are too long for the multi-step sweeps", (unsigned long long)nx);
-    const uint64_t W = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>() : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
     const uint64_t rows = y_hi - y_lo;
+    // Periodic lattices small enough to live in the caches take their launches of five steps (what
+    // lbm_plan_steps gives them) with halos of whole lanes instead of whole 32-byte granules where
+    // that makes fewer strips (lbm::fused_halo_lanes): 1024^2 fp32 144 -> 153 GLUPS, fp64 88 -> 91;
+    // with the same number of strips the ragged line ends cost 2-4 % (512^2, 768^2), and the cavity
+    // gains nothing (1024^2 push 121 -> 119).  LBM_FUSED_NARROW=0 (read at every launch) keeps the
+    // granule, 2 takes narrow halos whatever the strip count.
+    const uint64_t W_granule = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>()
+                                                        : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
+    const uint64_t W_narrow = lbm::kWave - 2 * lbm::fused_halo_lanes<T, V, lbm::kFusedNarrowSteps, true>();
+    const char *narrow_env = getenv("LBM_FUSED_NARROW");
+    const int narrow_mode = narrow_env ? atoi(narrow_env) : 1;
+    const bool narrow = k == lbm::kFusedNarrowSteps && !AOS && !LID && V * sizeof(T) == (size_t)lbm::kFusedLaneBytes &&
+                        nx * rows < kSmallLatticeNodes && narrow_mode != 0 &&
+                        (narrow_mode == 2 || (nx / V + W_narrow - 1) / W_narrow < (nx / V + W_granule - 1) / W_granule);
+    const uint64_t W = narrow ? W_narrow : W_granule;
     const uint64_t nstrips = (nx / V + W - 1) / W;
     uint64_t seg = g_fused_seg_rows ? g_fused_seg_rows : (k <= 2 ? 16 : k == 3 ? 32 : 128);
     bool small_grid = false;
@@ -607,6 +624,9 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         const unsigned nw = grouped ? (unsigned)lbm::fused_group_waves<T, V, KK, PUSH, LID, AOS, ARITH>() : 1u;  \
         const unsigned lds = nw * (unsigned)lbm::fused_lds_bytes_per_wave<T, V, KK, PUSH, LID, AOS, ARITH>();    \
         auto kern = lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>;                                               \
+        if constexpr (KK == lbm::kFusedNarrowSteps && !AOS && !LID && V * sizeof(T) == (size_t)lbm::kFusedLaneBytes) { \
+            if (narrow) kern = lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH, true>;                              \
+        }                                                                                                        \
         static std::atomic<bool> lds_allowed[kMaxDevicesForProps];                                               \
         if (lds > 64 * 1024 && !lds_allowed[dev].load()) {                                                       \
             const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1128,7 +1148,7 @@ int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remainin
     // of a wavefront; more steps lengthen the chain.  fp32 pull, GLUPS at 3/4/5/6/7/8 steps: 512^2
     // 50/56/57/53/52/49, 1024^2 107/128/144/137/136/133, 1536^2 135/160/197/203/212/213, 2048^2
     // 161/196/225/233/253/260.
-    if (dflt > 5 && nx * rows < (3ull << 19)) dflt = 5;
+    if (dflt > (uint64_t)lbm::kFusedNarrowSteps && nx * rows < kSmallLatticeNodes) dflt = (uint64_t)lbm::kFusedNarrowSteps;
     const char *m = getenv("LBM_FUSED_MAX_STEPS");
     uint64_t k = m ? strtoull(m, nullptr, 10) : dflt;
     if (k < 1) k = 1;

@@ -85,11 +85,18 @@ constexpr int kFusedMaxSteps = 8;    // 16384^2 fp32 pull, GLUPS at 5/6/7/8 step
                                      // contracted 326/377/410/424; fp64 contracted 154/162/167/171 (five steps and fewer run
                                      // at the memory roof, each further step costs less than it saves until the rings of
                                      // nine or more steps would cut the residency)
-// halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules
-template <typename T, int V, int K> constexpr int fused_halo_lanes()
+// halo lanes per strip side for K steps: K nodes, rounded up to whole 32-byte granules -- or, NARROW,
+// to whole lanes only.  Narrow halos leave 58 (fp64: 54) stored lanes at five steps where the
+// granule leaves 56 (48); their strips end inside 64-byte lines, which costs a lattice that streams
+// from HBM a fifth of its rate and a lattice that lives in the caches nothing: 1024-node rows are 9
+// strips instead of 10, and a 1024^2 launch of five steps runs in 29 us instead of 31.
+template <typename T, int V, int K, bool NARROW = false> constexpr int fused_halo_lanes()
 {
-    return ((K * (int)sizeof(T) + kFusedHaloBytes - 1) / kFusedHaloBytes) * kFusedHaloBytes / (V * (int)sizeof(T));
+    constexpr int granule = NARROW ? V * (int)sizeof(T) : kFusedHaloBytes;
+    return ((K * (int)sizeof(T) + granule - 1) / granule) * granule / (V * (int)sizeof(T));
 }
+// The one step count built with narrow halos: what small lattices take per launch (lbm_plan_steps).
+constexpr int kFusedNarrowSteps = 5;
 
 // Rings kept in registers.  With row addresses in scalar registers (row_load / row_store) the
 // periodic fp32 kernels have room for four (16384^2, eight steps: 2 rings 388 GLUPS, 3 rings 410,
@@ -366,13 +373,13 @@ struct RowIn {
 // populations like the push scheme does and streams every step in registers, the first one included.
 // ARITH: spelling of the relaxation (lbm_device.h).  kArithRolled is the reference's UNROLL_LOOPS=false
 // arithmetic (periodic scenes only, as there); kArithContracted the explicit fused multiply-adds.
-template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled>
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
                                            const T om, const T df_lid)
 {
     static_assert(V * sizeof(T) == kFusedLaneBytes || (V == 1 && sizeof(T) == 4),
                   "a lane owns kFusedLaneBytes of a row (one fp32 node when rows have an odd length)");
-    constexpr int H = fused_halo_lanes<T, V, K>();
+    constexpr int H = fused_halo_lanes<T, V, K, NARROW>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
     static_assert(H * V >= K, "x halo too narrow for K steps");
     constexpr bool OWN = PUSH || AOS;        // a row is loaded as its own nine populations
@@ -730,13 +737,14 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
 // scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
 // every instantiation fits without spilling (at most 239 VGPRs).
-template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled>
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false>
 __global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves) __attribute__((amdgpu_waves_per_eu(2)))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
     static_assert(ARITH != kArithContracted || !AOS, "the contracted arithmetic is built for [9][NY][NX] arrays only");
-    fused_body<T, V, K, PUSH, LID, AOS, ARITH>(f, buf, g, om, df_lid);
+    static_assert(!NARROW || (K == kFusedNarrowSteps && !AOS), "narrow halos are built for one step count");
+    fused_body<T, V, K, PUSH, LID, AOS, ARITH, NARROW>(f, buf, g, om, df_lid);
 }
 
 }  // namespace lbm

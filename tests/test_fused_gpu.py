@@ -197,3 +197,22 @@ def test_workgroups_of_several_wavefronts(grouped_launches, dtype, scene, scheme
             d_b = torch.full_like(d_f, float("nan"))
             run_fused(scene, scheme, d_f, d_b, 0.9, 0, ny, k, ny_glob=ny)
             assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {arith} {nx}x{ny} k={k} grouped")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,scheme", [("shear", "pull"), ("shear", "push")])
+@pytest.mark.parametrize("narrow", ["0", "1", "2"])
+def test_five_steps_with_either_halo_width(monkeypatch, dtype, scene, scheme, narrow):
+    """Small periodic lattices take launches of five steps with halos of whole lanes (58 stored lanes
+    per strip in fp32, 54 in fp64) where that makes fewer strips, everything else with halos of whole
+    32-byte granules (56 / 48); LBM_FUSED_NARROW=0 never takes narrow halos, 2 always.  Row lengths
+    around the strip widths of both."""
+    monkeypatch.setenv("LBM_FUSED_NARROW", narrow)
+    rng = np.random.default_rng(5 + (dtype == np.float64))
+    for nx, ny in [(116, 9), (118, 9), (112, 7), (108, 7), (54, 11), (56, 11), (1024, 40), (1044, 13), (522, 64)]:
+        f = random_state(rng, nx, ny, dtype)
+        want = oracle_steps(ONE_STEP[(scene, scheme)], f, 5, 1.1, dtype)
+        d_f = torch.from_numpy(f).cuda()
+        d_b = torch.full_like(d_f, float("nan"))
+        run_fused(scene, scheme, d_f, d_b, 1.1, 0, ny, 5, ny_glob=ny)
+        assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {nx}x{ny} five steps, narrow={narrow}")
