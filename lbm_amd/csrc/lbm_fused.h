@@ -145,6 +145,16 @@ constexpr int fused_group_waves()
     return 8 * fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>() <= 160 * 1024 ? kFusedMaxGroupWaves : 1;
 }
 
+// Most wavefronts a SIMD can hold of a kernel: what the LDS of the compute unit allows, spread over
+// its four SIMDs and rounded up; 8 (the hardware's limit) for kernels without rings in LDS.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_max_waves_per_simd()
+{
+    constexpr int lds = fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>();
+    constexpr int per_simd = lds == 0 ? 8 : (160 * 1024 / (lds == 0 ? 1 : lds) + 3) / 4;
+    return per_simd < 2 ? 2 : (per_simd > 8 ? 8 : per_simd);
+}
+
 // The LDS of a workgroup, carved up by fused_body.
 extern __shared__ __align__(16) unsigned char fused_lds_raw[];
 
@@ -735,10 +745,15 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 }
 
 // At least two wavefronts per SIMD (at most 256 VGPRs): a lone wavefront cannot overlap its own
-// scalar bookkeeping, memory issue and hazard stalls with vector work.  With two register rings
-// every instantiation fits without spilling (at most 239 VGPRs).
+// scalar bookkeeping, memory issue and hazard stalls with vector work.  Kernels with rings in LDS
+// are also told the most a SIMD can hold (fused_max_waves_per_simd): their residency is set by the
+// LDS (rolled push, seven steps: seven wavefronts per compute unit), which the compiler cannot see
+// in a dynamic allocation, and an instantiation of 160 VGPRs or fewer would otherwise let the
+// dispatcher stack three wavefronts on one SIMD and leave another with one (that kernel, 158 VGPRs:
+// 236 -> 223 GLUPS).
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false>
-__global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves)
+    __attribute__((amdgpu_waves_per_eu(2, fused_max_waves_per_simd<T, V, K, PUSH, LID, AOS, ARITH>())))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");

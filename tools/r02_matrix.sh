@@ -36,6 +36,10 @@ for ar in unrolled contracted; do
   bench --precision fp64 --arithmetic $ar
   bench --precision fp64 --scheme push --arithmetic $ar
   bench --max-fuse 1 --arithmetic $ar
+  say "smaller lattices (fp32 pull; 1024^2 also cavity push and fp64)"
+  for n in 512 1024 1536 2048 4096; do bench --nx $n --ny-global $n --steps 1000 --warmup 100 --arithmetic $ar; done
+  bench --nx 1024 --ny-global 1024 --steps 1000 --warmup 100 --scene lid --scheme push --arithmetic $ar
+  bench --nx 1024 --ny-global 1024 --steps 1000 --warmup 100 --precision fp64 --arithmetic $ar
 done
 say "== [NY][NX][9] arrays and the rolled arithmetic (strict rounding)"
 bench --layout aos
