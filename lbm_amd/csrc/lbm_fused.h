@@ -100,17 +100,20 @@ constexpr int kFusedNarrowSteps = 5;
 
 // Rings kept in registers.  With row addresses in scalar registers (row_load / row_store) the
 // periodic fp32 kernels have room for four (16384^2, eight steps: 2 rings 388 GLUPS, 3 rings 410,
-// 4 rings 412; push 344 / 388 / 411).  Everything else keeps two: the fp64 kernels spill a few
-// registers with three (and run 2 % faster all the same) and badly with four (171 -> 81 GLUPS), the
-// rolled arithmetic spills with four, the cavity kernels carry the wall cases in registers as well
-// (fp32 push: three fit, pull: two).
+// 4 rings 412; push 344 / 388 / 411).  The fp64 push kernels hold three from four steps on (seven
+// steps: 244 VGPRs; with one ring fewer in LDS a group of four wavefronts fits the compute unit
+// twice, see fused_group_waves: 158 -> 173 GLUPS) and two at three steps, where a third spills; the
+// fp64 pull kernels spill with three (-2 %) and badly with four (171 -> 81 GLUPS), the rolled
+// arithmetic spills with four, the cavity kernels carry the wall cases in registers as well (fp32
+// push: three fit, pull: two).
 // No instantiation of the library uses scratch memory.
-template <typename T, int V, bool PUSH, bool LID, bool AOS, int ARITH>
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
 constexpr int fused_reg_rings()
 {
     constexpr int forced = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
     if (forced > 0) return forced;
-    if (AOS || ARITH == kArithRolled || sizeof(T) == 8) return 2;
+    if (AOS || ARITH == kArithRolled) return 2;
+    if (sizeof(T) == 8) return PUSH && K >= 4 ? 3 : 2;
     if (LID) return PUSH ? 3 : 2;      // pull cavity kernels spill with three from six steps on
     return 4;
 }
@@ -122,7 +125,7 @@ template <int K, bool PUSH, bool AOS> constexpr int fused_ring_steps() { return 
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
 constexpr int fused_lds_bytes_per_wave()
 {
-    constexpr int rings = fused_ring_steps<K, PUSH, AOS>() - fused_reg_rings<T, V, PUSH, LID, AOS, ARITH>();
+    constexpr int rings = fused_ring_steps<K, PUSH, AOS>() - fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
     return (rings > 0 ? rings : 0) * 9 * kWave * V * (int)sizeof(T);
 }
 
@@ -526,7 +529,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // iteration instead of being copied.  Measured at 16384^2 fp32: with two register rings K=4 runs
     // as fast as with all rings in registers and K=5/6 become possible (K=6: +12 %); with three
     // register rings the pull kernels of K>=5 spill.
-    constexpr int kRegRings = fused_reg_rings<T, V, PUSH, LID, AOS, ARITH>();
+    constexpr int kRegRings = fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
     constexpr int NLDS = NG > kRegRings ? NG - kRegRings : 0;
     constexpr int NREG = NG - NLDS > 0 ? NG - NLDS : 1;
     typedef typename VecTypes<T, V>::vec_t ring_vec_t;
