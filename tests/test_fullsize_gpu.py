@@ -56,8 +56,9 @@ def test_shear_wave_32768x4096_fp32_pull_equals_narrow_oracle():
 
 
 def test_config5_shear_wave_32768sq_fp32_pull_equals_narrow_oracle():
-    """BASELINE config 5 at its own size on one device (2 x 38.65 GB resident): 12 steps, every one
-    of the 32768 columns bit-equal to the oracle's 8-column run, max |u| and mass included."""
+    """The 32768 x 32768 shear wave of the multi-GPU scaling runs at its own size on one device
+    (2 x 38.65 GB resident): 12 steps, every one of the 32768 columns bit-equal to the oracle's
+    8-column run, max |u| and mass included."""
     from lbm_amd import Simulation
     nx = ny = 32768
     steps, omega = 12, 0.5
@@ -120,8 +121,8 @@ def test_pull_and_push_velocities_agree_at_full_size():
 
 @pytest.mark.parametrize("scheme", ["push", "pull"])
 def test_config2_lid_cavity_1024sq_fp32_equals_oracle(scheme):
-    """BASELINE config 2 (`-ld -nx 1024 -ny 1024 -u 0.1`, fp32): populations and the velocity field
-    after 3000 steps, bit for bit against the CPU oracle run of the whole cavity (the reference's
+    """The lid-driven cavity the reference documents (`-ld -nx 1024 -ny 1024 -u 0.1`, fp32):
+    populations and the velocity field after 3000 steps, bit for bit against the CPU oracle run of the whole cavity (the reference's
     command runs 10000 steps; the oracle would need half a minute of host time for that)."""
     from lbm_amd import Simulation
     nx = ny = 1024
