@@ -193,10 +193,10 @@ int lbm_fused_max_steps(int prec, uint64_t nx);
  * LBM_FUSED_MIN_NODES makes lattices below that many nodes take one step per launch.  The time loops of this library's drivers (main.cpp:64-83) ask this before
  * every launch. */
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining);
-/* The same for a named scene: lid != 0 plans the lid-driven cavity sweeps (lbm_*_lid_fused), whose
- * kernels carry the wall cases in registers and pay for an eighth step where the periodic ones
- * still gain from it (16384^2 fp32, contracted: seven steps 397 / 399 GLUPS pull / push, eight 394 /
- * 380).  lbm_plan_steps() is this with lid = 0. */
+/* The same for a named scene: lid != 0 plans the lid-driven cavity sweeps (lbm_*_lid_fused).  The two
+ * scenes are planned alike at present (the cavity kernels run the periodic sweep's code in every
+ * wavefront that is eight nodes or more from a wall); callers that know their scene should say so.
+ * lbm_plan_steps() is this with lid = 0. */
 int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remaining, int lid);
 
 /* nsteps x pull_periodic (pull-push.cpp:5-73, :268-288). */

@@ -608,6 +608,10 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
     g.xcd_map = g_fused_xcd;
+    // LBM_FUSED_BULK=0 (read at every launch; tests): every wavefront of a cavity launch runs the code
+    // with the wall cases
+    const char *bulk_env = getenv("LBM_FUSED_BULK");
+    g.bulk_code = bulk_env ? atoi(bulk_env) : 1;
     g.seg_rows_wall = (uint32_t)seg_wall; g.nsegs_wall = (uint32_t)nsegs_wall;
     const uint64_t nsegs_grid = g.xcd_map ? (nsegs + 7) / 8 * 8 : nsegs;
     const uint64_t nwall = nstrips < 2 ? nstrips : 2;
@@ -1139,11 +1143,13 @@ int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remainin
     // Large lattices (16384^2, GLUPS at 6/7/8 steps): fp32 strict 325/334/335, contracted 377/410/424
     // (push 372/401/411); fp64 contracted pull 162/167/171, push 159/166/162.  The strict and rolled
     // spellings and the fp64 sweeps take seven (an eighth step gains little or nothing and deepens
-    // the halos of a decomposed run), contracted fp32 eight -- seven in the cavity, whose kernels
-    // keep the wall cases in registers and one ring more in LDS (seven steps 397 / 399 GLUPS pull /
-    // push, eight 394 / 380).
+    // the halos of a decomposed run), contracted fp32 eight.  The cavity is planned like the periodic
+    // scene: all but its outermost wavefronts run the periodic sweep's code (16384^2 fp32
+    // contracted, seven / eight steps: pull 391 / 416 GLUPS, push 397 / 412); `lid` is kept for
+    // kernels that may differ again.
+    (void)lid;
     uint64_t dflt = (uint64_t)kmax;
-    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64 || lid)) dflt = 7;
+    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
     // Small lattices (one round of wavefronts or less) are bound by the chain of dependent iterations
     // of a wavefront; more steps lengthen the chain.  fp32 pull, GLUPS at 3/4/5/6/7/8 steps: 512^2
     // 50/56/57/53/52/49, 1024^2 107/128/144/137/136/133, 1536^2 135/160/197/203/212/213, 2048^2

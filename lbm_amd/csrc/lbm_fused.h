@@ -45,6 +45,8 @@
 // iteration makes one wave-uniform test and runs either the periodic code or the code with the wall
 // cases in it (fused_body::iteration): testing inside every streaming step cost the fp64 sweeps
 // 12 % (16384^2, six steps: 132 -> 149 GLUPS with this and the DPP change below).
+// Wavefronts whose stored nodes lie K nodes or more from every wall do not run that code at all but
+// the periodic sweep's (k_fused): nothing a wall has touched within K steps reaches what they store.
 //
 // Array-of-structures lattices ([NY][NX][9]): same kernels, other load / store code (load_aos).
 #pragma once
@@ -124,11 +126,28 @@ constexpr int fused_reg_rings()
 // Streaming steps done in registers or LDS (everything but the step that reads memory).
 template <int K, bool PUSH, bool AOS> constexpr int fused_ring_steps() { return (PUSH || AOS) ? K : K - 1; }
 
-// LDS of one wavefront: the rings that do not live in registers (4.5 KiB each).
+// Cavity kernels on [9][NY][NX] arrays run the periodic sweep's code in wavefronts far from every
+// wall (k_fused).
+template <bool LID, bool AOS> constexpr bool fused_cavity_bulk() { return LID && !AOS; }
+// Register rings of that code inside a cavity kernel: the periodic sweep's own choice, but three
+// where that is four in a pull kernel (next to the wall code's registers a fourth ring spills; as a
+// kernel of its own the periodic sweep loses half a percent with three).
+template <typename T, int V, int K, bool PUSH, bool AOS, int ARITH>
+constexpr int fused_bulk_rings()
+{
+    constexpr int r = fused_reg_rings<T, V, K, PUSH, false, AOS, ARITH>();
+    return (!PUSH && r > 3) ? 3 : r;
+}
+
+// LDS of one wavefront: the rings that do not live in registers (4.5 KiB each); for a cavity kernel
+// the larger of its two bodies' needs.
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
 constexpr int fused_lds_bytes_per_wave()
 {
-    constexpr int rings = fused_ring_steps<K, PUSH, AOS>() - fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
+    constexpr int steps = fused_ring_steps<K, PUSH, AOS>();
+    constexpr int own = steps - fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
+    constexpr int bulk = fused_cavity_bulk<LID, AOS>() ? steps - fused_bulk_rings<T, V, K, PUSH, AOS, ARITH>() : 0;
+    constexpr int rings = own > bulk ? own : bulk;
     return (rings > 0 ? rings : 0) * 9 * kWave * V * (int)sizeof(T);
 }
 
@@ -170,7 +189,8 @@ struct FusedGeom {
     int wrap_y;             // rows outside [0,ny) wrap around (whole periodic lattice on this device)
     uint32_t seg_rows;      // rows stored per wavefront
     uint32_t nstrips, nsegs;
-    int xcd_map;            // != 0: deal whole segments to the XCDs (see fused_body)
+    int xcd_map;            // != 0: deal whole segments to the XCDs (see fused_work)
+    int bulk_code;          // cavity: != 0 lets wavefronts far from every wall run the periodic sweep's code (k_fused)
     int64_t y_goff;         // lid scenes: global row = row + y_goff
     uint64_t ny_glob;       //             cavity height
     // lid scenes on small grids: the strips at the side walls run the slower code with the wall
@@ -384,14 +404,70 @@ struct RowIn {
     T w[2];         // lid pull, outermost strips: the row's own 6 at x = 0 and own 5 at x = nx-1
 };
 
+// What one wavefront of a launch works on.
+struct FusedWork {
+    uint32_t wave;          // index of the wavefront in its workgroup
+    uint32_t strip, seg;    // strip of 64 lanes along x, segment of rows along y
+    uint32_t seg_rows;      // rows per segment for this strip
+    uint32_t lds_base;      // byte offset of this wavefront's part of the workgroup's LDS (set by the kernel)
+    bool valid;             // false: the launch was rounded up, nothing to do
+};
+
+// A workgroup of several wavefronts stands for as many consecutive single-wavefront blocks; the
+// wavefront's index is read into a scalar register, since row addresses must stay wave-uniform.
+// Blocks are numbered strip fastest, and workgroups go to the 8 XCDs round-robin: the strips of
+// one group share their common lines in one L2, the neighbours across a group boundary do not.
+// xcd_map (single wavefronts only): XCD j takes segments j, j+8, ... and walks all strips of a
+// segment in order, so every shared line meets its second reader in the same L2.  Measured at
+// 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every segment's strips
+// instead): address-order dispatch is worth more than the shared lines.
+template <bool LID>
+__device__ __forceinline__ FusedWork fused_work(const FusedGeom &g)
+{
+    FusedWork w;
+    w.wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t block = blockIdx.x * (blockDim.x / kWave) + w.wave;
+    uint32_t nsegs = g.nsegs;
+    w.seg_rows = g.seg_rows;
+    if (LID && g.nsegs_wall != 0) {
+        // first the wall strips with their own (shorter) segments -- the slowest wavefronts start
+        // first --, then the strips without walls, segment by segment
+        const uint32_t nwall = g.nstrips < 2 ? g.nstrips : 2u, nmid = g.nstrips - nwall;
+        const uint32_t wall_blocks = nwall * g.nsegs_wall;
+        if (block < wall_blocks) {
+            w.strip = (block % nwall) ? g.nstrips - 1 : 0u;
+            w.seg = block / nwall;
+            w.seg_rows = g.seg_rows_wall;
+            nsegs = g.nsegs_wall;
+        } else {
+            const uint32_t b = block - wall_blocks;
+            w.strip = 1 + b % nmid;
+            w.seg = b / nmid;
+        }
+    } else if (g.xcd_map) {
+        const uint32_t xcd = block & 7u, slot = block >> 3;
+        w.seg = (slot / g.nstrips) * 8 + xcd;
+        w.strip = slot % g.nstrips;
+    } else {
+        w.strip = block % g.nstrips;
+        w.seg = block / g.nstrips;
+    }
+    w.lds_base = 0;
+    w.valid = w.seg < nsegs;
+    return w;
+}
+
 // K time steps of one scene/scheme.  nstrips * nsegs wavefronts, in workgroups of blockDim.x / 64.
 // AOS: the arrays are [NY][NX][9].  The pull scheme then reads each row's own nine (post-collision)
 // populations like the push scheme does and streams every step in registers, the first one included.
 // ARITH: spelling of the relaxation (lbm_device.h).  kArithRolled is the reference's UNROLL_LOOPS=false
 // arithmetic (periodic scenes only, as there); kArithContracted the explicit fused multiply-adds.
-template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false>
+// NARROW: halos of whole lanes (fused_halo_lanes).  RINGS: rings kept in registers, 0 = fused_reg_rings().
+// `work` names the strip and segment of this wavefront and its part of the workgroup's LDS.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false,
+          int RINGS = 0>
 __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom &g,
-                                           const T om, const T df_lid)
+                                           const FusedWork &work, const T om, const T df_lid)
 {
     static_assert(V * sizeof(T) == kFusedLaneBytes || (V == 1 && sizeof(T) == 4),
                   "a lane owns kFusedLaneBytes of a row (one fp32 node when rows have an odd length)");
@@ -403,41 +479,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     constexpr int D = NG;                    // rows between a segment's first row and the first row relaxed
     constexpr int NR = NG > 0 ? NG : 1;
 
-    // A workgroup of several wavefronts stands for as many consecutive single-wavefront blocks; the
-    // wavefront's index is read into a scalar register, since row addresses must stay wave-uniform.
-    // Blocks are numbered strip fastest, and workgroups go to the 8 XCDs round-robin: the strips of
-    // one group share their common lines in one L2, the neighbours across a group boundary do not.
-    // xcd_map (single wavefronts only): XCD j takes segments j, j+8, ... and walks all strips of a
-    // segment in order, so every shared line meets its second reader in the same L2.  Measured at
-    // 16384^2 fp32: -3 % (and -10 % when each XCD takes a contiguous eighth of every segment's strips
-    // instead): address-order dispatch is worth more than the shared lines.
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const uint32_t block = blockIdx.x * (blockDim.x / kWave) + wave;
-    uint32_t strip, seg, seg_rows = g.seg_rows, nsegs = g.nsegs;
-    if (LID && g.nsegs_wall != 0) {
-        // first the wall strips with their own (shorter) segments -- the slowest wavefronts start
-        // first --, then the strips without walls, segment by segment
-        const uint32_t nwall = g.nstrips < 2 ? g.nstrips : 2u, nmid = g.nstrips - nwall;
-        const uint32_t wall_blocks = nwall * g.nsegs_wall;
-        if (block < wall_blocks) {
-            strip = (block % nwall) ? g.nstrips - 1 : 0u;
-            seg = block / nwall;
-            seg_rows = g.seg_rows_wall;
-            nsegs = g.nsegs_wall;
-        } else {
-            const uint32_t b = block - wall_blocks;
-            strip = 1 + b % nmid;
-            seg = b / nmid;
-        }
-    } else if (g.xcd_map) {
-        const uint32_t xcd = block & 7u, slot = block >> 3;
-        seg = (slot / g.nstrips) * 8 + xcd;
-        strip = slot % g.nstrips;
-    } else {
-        strip = block % g.nstrips;
-        seg = block / g.nstrips;
-    }
-    if (seg >= nsegs) return;
+    const uint32_t strip = work.strip, seg = work.seg, seg_rows = work.seg_rows;
     const uint32_t lane = threadIdx.x % kWave;
     const uint32_t nxv = g.nx / V;
     int64_t vx = (int64_t)strip * W - H + (int64_t)lane;
@@ -532,13 +574,13 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // iteration instead of being copied.  Measured at 16384^2 fp32: with two register rings K=4 runs
     // as fast as with all rings in registers and K=5/6 become possible (K=6: +12 %); with three
     // register rings the pull kernels of K>=5 spill.
-    constexpr int kRegRings = fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
+    constexpr int kRegRings = RINGS > 0 ? RINGS : fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
     constexpr int NLDS = NG > kRegRings ? NG - kRegRings : 0;
     constexpr int NREG = NG - NLDS > 0 ? NG - NLDS : 1;
     typedef typename VecTypes<T, V>::vec_t ring_vec_t;
     // this wavefront's part of the workgroup's LDS: [ring][set*3 + k | 6 + k][lane]
     ring_vec_t (*ring_lds)[9][kWave] = reinterpret_cast<ring_vec_t (*)[9][kWave]>(
-        fused_lds_raw + wave * (uint32_t)fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>());
+        fused_lds_raw + work.lds_base);
     T ringA[NREG][3][V], ringB[NREG][3][V], ringC[NREG][3][V], ring7[NR], ring8[NR];
 #pragma unroll
     for (int s = 0; s < NREG; ++s) {
@@ -765,7 +807,32 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
     static_assert(ARITH != kArithContracted || !AOS, "the contracted arithmetic is built for [9][NY][NX] arrays only");
     static_assert(!NARROW || (K == kFusedNarrowSteps && !AOS), "narrow halos are built for one step count");
-    fused_body<T, V, K, PUSH, LID, AOS, ARITH, NARROW>(f, buf, g, om, df_lid);
+    FusedWork work = fused_work<LID>(g);
+    if (!work.valid) return;
+    work.lds_base = work.wave * (uint32_t)fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>();
+    if constexpr (fused_cavity_bulk<LID, AOS>()) {
+        // Cavity: a wavefront whose stored nodes lie K nodes or more from every wall computes nothing
+        // that a wall has touched within K steps (walls act on the wall nodes only), and what its
+        // halo lanes and rows compute nearer to a wall -- wrongly, without the wall cases -- lies
+        // outside the dependency cone of what it stores.  It runs the periodic sweep's code (rows
+        // clamped into the array: the launch has wrap_y = 0), which has no wall cases to carry in
+        // registers and keeps a ring more there.  One wave-uniform test per wavefront.
+        constexpr int W = kWave - 2 * fused_halo_lanes<T, V, K, NARROW>();
+        const uint32_t nxv = g.nx / V;
+        const uint32_t first = work.strip * W * V;
+        const uint32_t end_v = (work.strip + 1) * W;
+        const uint32_t last = (end_v < nxv ? end_v : nxv) * V - 1;
+        const uint32_t ys = g.y_lo + work.seg * work.seg_rows;
+        const uint32_t ye = min(ys + work.seg_rows, g.y_hi);
+        const int64_t gy0 = (int64_t)ys + g.y_goff, gy1 = (int64_t)ye - 1 + g.y_goff;
+        const bool bulk = g.bulk_code != 0 && first >= (uint32_t)K && (uint64_t)last + K <= (uint64_t)g.nx - 1 &&
+                          gy0 >= K && gy1 + K <= (int64_t)g.ny_glob - 1;
+        if (bulk) {
+            fused_body<T, V, K, PUSH, false, AOS, ARITH, NARROW, fused_bulk_rings<T, V, K, PUSH, AOS, ARITH>()>(f, buf, g, work, om, df_lid);
+            return;
+        }
+    }
+    fused_body<T, V, K, PUSH, LID, AOS, ARITH, NARROW>(f, buf, g, work, om, df_lid);
 }
 
 }  // namespace lbm

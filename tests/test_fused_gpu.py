@@ -216,3 +216,30 @@ def test_five_steps_with_either_halo_width(monkeypatch, dtype, scene, scheme, na
         d_b = torch.full_like(d_f, float("nan"))
         run_fused(scene, scheme, d_f, d_b, 1.1, 0, ny, 5, ny_glob=ny)
         assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {nx}x{ny} five steps, narrow={narrow}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+@pytest.mark.parametrize("k", [3, 5, 7, 8])
+@pytest.mark.parametrize("bulk", ["0", "1"])
+def test_cavity_with_and_without_the_periodic_code_in_its_bulk(monkeypatch, dtype, scheme, k, bulk):
+    """Cavities wide and high enough to have wavefronts k nodes or more from every wall: those run the
+    periodic sweep's code (LBM_FUSED_BULK=1, the default) or, like everybody else, the code with the
+    wall cases (0).  Both must give the oracle's populations; whole cavities and a row range with a
+    global offset (a slab of a higher cavity)."""
+    monkeypatch.setenv("LBM_FUSED_BULK", bulk)
+    rng = np.random.default_rng(3 * k + (dtype == np.float64))
+    name = ONE_STEP[("lid", scheme)]
+    for nx, ny in [(1536, 300), (700, 420)]:
+        f = random_state(rng, nx, ny, dtype)
+        want = oracle_steps(name, f, k, 1.3, dtype)
+        d_f = torch.from_numpy(f).cuda()
+        d_b = torch.full_like(d_f, float("nan"))
+        run_fused("lid", scheme, d_f, d_b, 1.3, 0, ny, k, ny_glob=ny)
+        assert_bits_equal(d_b.cpu().numpy(), want, f"lid {scheme} {nx}x{ny} k={k} bulk={bulk}")
+        # rows [100, 260) of the same cavity, held in an array that starts at global row 100 - k
+        lo, hi = 100 - k, 260 + k
+        d_s = torch.from_numpy(np.ascontiguousarray(f[:, lo:hi])).cuda()
+        d_o = torch.full_like(d_s, -7.0)
+        run_fused("lid", scheme, d_s, d_o, 1.3, k, k + 160, k, y_goff=lo, ny_glob=ny)
+        assert_bits_equal(d_o.cpu().numpy()[:, k:k + 160], want[:, 100:260], f"lid {scheme} {nx}x{ny} k={k} rows 100:260 bulk={bulk}")

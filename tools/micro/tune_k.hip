@@ -46,7 +46,7 @@ template <int K>
 void add(std::vector<Variant> &vs, uint32_t nx, uint32_t ny, T om, uint32_t seg_rows)
 {
     constexpr int W = 64 - 2 * fused_halo_lanes<T, V, K>();
-    FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0, 0, 0, 0};
+    FusedGeom g{nx, ny, 0, ny, 1, seg_rows, (nx / V + W - 1) / W, (ny + seg_rows - 1) / seg_rows, 0, 0, 0, 0, 0, 0};
     constexpr unsigned NW = (unsigned)fused_group_waves<T, V, K, TK_PUSH, false, false, TK_ARITH>();
     constexpr unsigned lds = NW * (unsigned)fused_lds_bytes_per_wave<T, V, K, TK_PUSH, false, false, TK_ARITH>();
     const dim3 grid((g.nstrips * g.nsegs + NW - 1) / NW);
