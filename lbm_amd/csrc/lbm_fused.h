@@ -127,8 +127,10 @@ constexpr int fused_reg_rings()
 template <int K, bool PUSH, bool AOS> constexpr int fused_ring_steps() { return (PUSH || AOS) ? K : K - 1; }
 
 // Cavity kernels on [9][NY][NX] arrays run the periodic sweep's code in wavefronts far from every
-// wall (k_fused).
-template <bool LID, bool AOS> constexpr bool fused_cavity_bulk() { return LID && !AOS; }
+// wall (k_fused) -- from six steps on: launches of five steps and fewer are what small cavities
+// take, which gain nothing from it (1024^2: +-1 %) and lose 4 % to the larger kernel (cfg: `-ld
+// -nx 1024 -ny 1024`, 136 -> 129 GLUPS).
+template <bool LID, bool AOS, int K> constexpr bool fused_cavity_bulk() { return LID && !AOS && K > kFusedNarrowSteps; }
 // Register rings of that code inside a cavity kernel: the periodic sweep's own choice, but three
 // where that is four in a pull kernel (next to the wall code's registers a fourth ring spills; as a
 // kernel of its own the periodic sweep loses half a percent with three).
@@ -146,7 +148,7 @@ constexpr int fused_lds_bytes_per_wave()
 {
     constexpr int steps = fused_ring_steps<K, PUSH, AOS>();
     constexpr int own = steps - fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
-    constexpr int bulk = fused_cavity_bulk<LID, AOS>() ? steps - fused_bulk_rings<T, V, K, PUSH, AOS, ARITH>() : 0;
+    constexpr int bulk = fused_cavity_bulk<LID, AOS, K>() ? steps - fused_bulk_rings<T, V, K, PUSH, AOS, ARITH>() : 0;
     constexpr int rings = own > bulk ? own : bulk;
     return (rings > 0 ? rings : 0) * 9 * kWave * V * (int)sizeof(T);
 }
@@ -810,7 +812,7 @@ k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T
     FusedWork work = fused_work<LID>(g);
     if (!work.valid) return;
     work.lds_base = work.wave * (uint32_t)fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>();
-    if constexpr (fused_cavity_bulk<LID, AOS>()) {
+    if constexpr (fused_cavity_bulk<LID, AOS, K>()) {
         // Cavity: a wavefront whose stored nodes lie K nodes or more from every wall computes nothing
         // that a wall has touched within K steps (walls act on the wall nodes only), and what its
         // halo lanes and rows compute nearer to a wall -- wrongly, without the wall cases -- lies
