@@ -31,7 +31,8 @@ The JSON line also carries
                 names the larger of the two floors and `frac_of_binding_roof` = that floor / the
                 measured launch time.  Both floors are priced at the peaks; the same profile also
                 records what the part delivers (copy ceiling 6.2 TB/s, engine clock under this load
-                ~1.8-2.0 GHz): `hbm_frac_of_copy_ceiling`, `valu.frac_at_profiled_clock`;
+                ~1.8-2.0 GHz): `hbm_frac_of_copy_ceiling`, `valu.frac_at_profiled_clock`, and the larger
+                of those two floors as `binding_as_delivered` / `frac_of_binding_roof_as_delivered`;
   parity:       after the timed region every rank compares its rows with the CPU oracle's run of the
                 same global lattice (8 columns wide: the shear wave is x-invariant, so every column
                 of the GPU state must equal the oracle's column bit for bit);
@@ -381,6 +382,11 @@ def main():
         if valu_floor_s:
             floors["valu"] = valu_floor_s
         binding = max(floors, key=floors.get)
+        # the same two floors at what the part delivers: copy ceiling for the bytes, the profiled clock for the issue
+        delivered = {"hbm": hbm_floor_s * HBM_PEAK_GBS / COPY_CEILING_GBS}
+        if valu_floor_seen_s:
+            delivered["valu"] = valu_floor_seen_s
+        binding_delivered = max(delivered, key=delivered.get)
         out = {
             "metric": "MLUPS",
             "value": mlups,
@@ -438,6 +444,8 @@ def main():
                 "valu_frac": (valu_floor_s / launch_s) if valu_floor_s else None,
                 "binding": binding,
                 "frac_of_binding_roof": floors[binding] / launch_s,
+                "binding_as_delivered": binding_delivered,
+                "frac_of_binding_roof_as_delivered": delivered[binding_delivered] / launch_s,
                 "profile": prof.get("source"),
                 "launch_ms": launch_s * 1e3,
                 "note": ("one launch advances several time steps per pass over HBM, so the algorithmic rate "
