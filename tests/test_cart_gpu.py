@@ -2,6 +2,7 @@
 block with a halo ring, the packing and the second stream -- first with the rank as its own
 neighbour in both directions, then four and six ranks sharing cuda:0 over gloo (RCCL refuses
 several ranks on one GPU)."""
+import faulthandler
 import os
 import sys
 import tempfile
@@ -40,6 +41,8 @@ CASES = [("float32", 256, 96, 30, 0.8), ("float64", 67, 45, 40, 1.3), ("float32"
 
 def _worker(rank, world, store_path, out_path):
     sys.path.insert(0, ROOT)
+    # a rank that stops making progress prints its stacks and exits: the test fails, the suite goes on
+    faulthandler.dump_traceback_later(100, exit=True)
     from lbm_amd.cart import CartSimulation
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
@@ -62,7 +65,7 @@ def _worker(rank, world, store_path, out_path):
 
 
 @pytest.mark.parametrize("world", [4, 6])
-def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world):
+def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world, ranks_share_one_gpu):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "out.pt")
         mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), out), nprocs=world, join=True)

@@ -1,6 +1,7 @@
 """Two ranks sharing cuda:0 over gloo: the GPU slab path (HIP kernels, second stream, events) under
 a real multi-process exchange.  RCCL refuses two ranks on one GPU, so the transport here is gloo;
 what is exercised is everything else of lbm_amd.slab on the device."""
+import faulthandler
 import os
 import sys
 import tempfile
@@ -14,6 +15,9 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# A rank that stops making progress prints every thread's stack and exits after this many seconds,
+# so a stall fails its test with the place it stalled in instead of hanging the suite.
+STALL_SECONDS = 100
 
 CASES = [
     ("shear", "pull", "float32", 256, 37, 30, 0.8),
@@ -26,6 +30,7 @@ CASES = [
 
 def _worker(rank, world, store_path, out_path):
     sys.path.insert(0, ROOT)
+    faulthandler.dump_traceback_later(STALL_SECONDS, exit=True)
     from lbm_amd.slab import SlabSimulation
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
@@ -52,6 +57,7 @@ def _worker_big(rank, world, store_path, out_dir):
     """Slabs large enough that the interior sweep really overlaps the exchange.  The shear wave is
     x-invariant, so each rank checks its rows against an 8-column oracle run of the global lattice."""
     sys.path.insert(0, ROOT)
+    faulthandler.dump_traceback_later(STALL_SECONDS, exit=True)
     from lbm_amd.slab import SlabSimulation
     from oracle import oracle as orc
     torch.cuda.set_device(0)
@@ -77,7 +83,7 @@ def _worker_big(rank, world, store_path, out_dir):
         dist.destroy_process_group()
 
 
-def test_four_ranks_with_real_overlap_work():
+def test_four_ranks_with_real_overlap_work(ranks_share_one_gpu):
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker_big, args=(4, os.path.join(tmp, "store"), tmp), nprocs=4, join=True)
         for r in range(4):
@@ -88,6 +94,7 @@ def _worker_rccl_self(rank, world, port, out_dir):
     """World of one over RCCL: the periodic neighbours are this rank itself, and the halo rows go
     through exactly the grouped send/recv on the second stream that a multi-GPU run uses."""
     sys.path.insert(0, ROOT)
+    faulthandler.dump_traceback_later(STALL_SECONDS, exit=True)
     from lbm_amd.slab import SlabSimulation
     from oracle import oracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -133,7 +140,7 @@ def test_rccl_transport_with_self_as_both_neighbours():
         assert open(os.path.join(tmp, "result.txt")).read() == "ok"
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_oracle():
+def test_two_ranks_on_one_gpu_reproduce_the_oracle(ranks_share_one_gpu):
     from oracle import oracle as orc
     with tempfile.TemporaryDirectory() as tmp:
         store, out = os.path.join(tmp, "store"), os.path.join(tmp, "out.pt")

@@ -2,7 +2,7 @@
 """Merge the summary of one tools/r02_profile_bench.sh run into profiles/pmc_traffic.json.
 
 usage: pmc_to_json.py gpurun_out/prof_TAG NX NY ROUND_TAG
-Every lbm::k_fused<T, V, K, PUSH, LID, AOS, ARITH> kernel of the summary becomes one entry keyed the way
+Every lbm::k_fused<T, V, K, PUSH, LID, AOS, ARITH[, NARROW]> kernel of the summary becomes one entry keyed the way
 bench.py looks profiles up: scene-scheme-precision-NXxNY[-aos][-rolled|-contracted][-fusedK]."""
 import json
 import os
@@ -19,10 +19,12 @@ def main():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     table = json.load(open(path))
     for kernel, c in summary.items():
-        m = re.search(r"k_fused<(float|double), (\d+), (\d+), (true|false), (true|false), (true|false), (\d+)>", kernel)
+        m = re.search(r"k_fused<(float|double), (\d+), (\d+), (true|false), (true|false), (true|false), (\d+)(?:, (true|false))?>", kernel)
         if not m or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
-        t, v, k, push, lid, aos, arith = m.groups()
+        t, v, k, push, lid, aos, arith, narrow = m.groups()
+        if narrow == "true":
+            continue   # halos of whole lanes: what small lattices run, not what bench.py looks up
         key = f"{'lid' if lid == 'true' else 'shear'}-{'push' if push == 'true' else 'pull'}-{'fp32' if t == 'float' else 'fp64'}-{nx}x{ny}"
         key += ("-aos" if aos == "true" else "") + {"0": "", "1": "-rolled", "2": "-contracted"}[arith]
         if int(k) != 1:
