@@ -227,8 +227,8 @@ def main():
     if args.rolled:
         ops.set_unroll_loops(False)
     if args.arithmetic == "contracted":
-        if args.rolled or args.layout == "aos":
-            raise SystemExit("--arithmetic contracted goes with neither --rolled nor --layout aos")
+        if args.rolled:
+            raise SystemExit("--arithmetic contracted does not go with --rolled")
         ops.set_arithmetic("contracted")
     if args.layout == "aos":
         if world != 1 or args.slab:

@@ -88,8 +88,9 @@ int lbm_get_unroll_loops(void);
  *                         reciprocal of the density (correctly rounded) and all other products are
  *                         unchanged.  A third fewer vector instructions per node.  Populations stay within the parity budget of
  *                         the unrolled spelling (fp32 1e-5, fp64 1e-12 max-abs over thousands of
- *                         steps; measured 3e-7 / 1e-15).  All sweeps on [9][NY][NX] arrays; fp32 rows
- *                         must have an even length >= 4 for the *_fused entry points.
+ *                         steps; measured 3e-7 / 1e-15).  All sweeps in both layouts; fp32 rows must
+ *                         have an even length >= 4 for the *_fused entry points (on [NY][NX][9]
+ *                         arrays for every sweep).
  * The environment variable LBM_ARITHMETIC (unrolled | rolled | contracted) sets the initial value. */
 enum { LBM_ARITH_UNROLLED = 0, LBM_ARITH_ROLLED = 1, LBM_ARITH_CONTRACTED = 2 };
 int lbm_set_arithmetic(int arithmetic);

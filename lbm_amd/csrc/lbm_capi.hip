@@ -683,12 +683,12 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
         }
     }
     if (g_arith == lbm::kArithContracted) {
-        if (g_layout == LBM_LAYOUT_AOS)
-            return fail(LBM_ERR_UNSUPPORTED, "the contracted arithmetic is not available on [NY][NX][9] arrays");
         if (narrow)
             return fail(LBM_ERR_UNSUPPORTED,
                         "the contracted arithmetic takes several steps per call only for fp32 rows of an even length >= 4 (nx=%llu)",
                         (unsigned long long)nx);
+        if (g_layout == LBM_LAYOUT_AOS)
+            return launch_fused<T, V8, PUSH, LID, true, lbm::kArithContracted>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
         return launch_fused<T, V8, PUSH, LID, false, lbm::kArithContracted>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
     }
     if (g_layout == LBM_LAYOUT_AOS) {
@@ -785,8 +785,12 @@ int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, d
     if (nx < 2)
         return fail(LBM_ERR_UNSUPPORTED, "[NY][NX][9] arrays need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
-    if ((!LID && g_arith == lbm::kArithRolled) || g_arith == lbm::kArithContracted)
-        return fail(LBM_ERR_UNSUPPORTED, "the rolled and contracted arithmetics are not available on [NY][NX][9] arrays");
+    if (!LID && g_arith == lbm::kArithRolled)
+        return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
+    if (g_arith == lbm::kArithContracted && prec == LBM_F32 && (nx % 2 != 0 || nx < 4))
+        return fail(LBM_ERR_UNSUPPORTED,
+                    "the contracted arithmetic on [NY][NX][9] arrays needs fp32 rows of an even length >= 4 (nx=%llu)",
+                    (unsigned long long)nx);
     const bool whole = y_lo == 0 && y_hi == ny && (LID ? (y_goff == 0 && ny_glob == ny) : wrap_y != 0);
     if (!PULL && !whole)
         return fail(LBM_ERR_UNSUPPORTED,
@@ -1120,8 +1124,10 @@ int lbm_fused_max_steps(int prec, uint64_t nx)
 {
     if (prec != LBM_F32 && prec != LBM_F64) return 0;
     bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
-    // the rolled arithmetic is built for 8-byte lanes only, and not for [NY][NX][9] arrays
-    if (g_arith != lbm::kArithUnrolled && (g_layout == LBM_LAYOUT_AOS || (prec == LBM_F32 && (nx % 2 != 0 || nx < 4)))) ok = false;
+    // the rolled and contracted arithmetics are built for 8-byte lanes only, the rolled one not for
+    // [NY][NX][9] arrays
+    if (g_arith != lbm::kArithUnrolled && prec == LBM_F32 && (nx % 2 != 0 || nx < 4)) ok = false;
+    if (g_arith == lbm::kArithRolled && g_layout == LBM_LAYOUT_AOS) ok = false;
     return ok ? max_fused_steps(prec) : 1;
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)

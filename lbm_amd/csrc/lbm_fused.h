@@ -107,8 +107,8 @@ constexpr int kFusedNarrowSteps = 5;
 // twice, see fused_group_waves: 158 -> 173 GLUPS) and two at three steps, where a third spills; the
 // fp64 pull kernels spill with three (-2 %) and badly with four (171 -> 81 GLUPS), the rolled
 // arithmetic holds three (push, seven steps: 252 -> 272 GLUPS for the same reason as fp64 push; pull
-// +1 %) and spills with four, the [NY][NX][9] kernels hold three in fp32 (two in the pull cavity) and spill
-// with three in fp64, the
+// +1 %) and spills with four, the [NY][NX][9] kernels hold three in fp32 (two in the pull cavity, and two
+// with the contracted arithmetic, whose schedule spills 12-24 bytes with three) and spill with three in fp64, the
 // cavity kernels carry the wall cases in registers as well (fp32 push: three fit, pull: two).
 // No instantiation of the library uses scratch memory.
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
@@ -116,7 +116,7 @@ constexpr int fused_reg_rings()
 {
     constexpr int forced = PUSH ? LBM_FUSED_REG_RINGS_PUSH : LBM_FUSED_REG_RINGS_PULL;
     if (forced > 0) return forced;
-    if (AOS) return (sizeof(T) == 4 && (PUSH || !LID)) ? 3 : 2;
+    if (AOS) return (sizeof(T) == 4 && (PUSH || !LID) && ARITH != kArithContracted) ? 3 : 2;
     if (ARITH == kArithRolled) return 3;
     if (sizeof(T) == 8) return PUSH && K >= 4 ? 3 : 2;
     if (LID) return PUSH ? 3 : 2;      // pull cavity kernels spill with three from six steps on
@@ -807,7 +807,6 @@ __global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves)
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
-    static_assert(ARITH != kArithContracted || !AOS, "the contracted arithmetic is built for [9][NY][NX] arrays only");
     static_assert(!NARROW || (K == kFusedNarrowSteps && !AOS), "narrow halos are built for one step count");
     FusedWork work = fused_work<LID>(g);
     if (!work.valid) return;

@@ -193,3 +193,40 @@ def test_simulation_runs_the_same_in_both_layouts(scene, scheme):
         assert torch.equal(s.velocities(), vel_a) and s.max_velocity() == max_a
         assert torch.equal(a.f.permute(2, 0, 1), s.f)
     assert a.launches == s.launches
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,scheme", list(ONE_STEP))
+@pytest.mark.parametrize("k", [1, 2, 5, 7, 8])
+def test_contracted_arithmetic_matches_its_oracle_restatement(dtype, scene, scheme, k):
+    """LBM_ARITH_CONTRACTED on [NY][NX][9] arrays: the bits of the oracle's operation-by-operation
+    restatement of the explicit contraction, as on [9][NY][NX] arrays; fp32 rows of an odd length
+    are refused."""
+    from lbm_amd import capi, ops
+    rng = np.random.default_rng(900 + k)
+    with orc.arithmetic("contracted"), ops.arithmetic("contracted"):
+        for nx, ny in SIZES:
+            if scene == "lid" and (ny < 2 or nx < 2):
+                continue
+            f = random_state(rng, nx, ny, dtype)
+            d_f = torch.from_numpy(to_aos(f)).cuda()
+            d_b = torch.full_like(d_f, float("nan"))
+            if dtype == np.float32 and (nx % 2 or nx < 4):
+                with pytest.raises(capi.LbmError, match="unsupported"):
+                    run_fused(scene, scheme, d_f, d_b, 1.3, 0, ny, k, wrap_y=True, y_goff=0, ny_glob=ny)
+                continue
+            want = oracle_steps(ONE_STEP[(scene, scheme)], f, k, 1.3, dtype)
+            run_fused(scene, scheme, d_f, d_b, 1.3, 0, ny, k, wrap_y=True, y_goff=0, ny_glob=ny)
+            assert_bits_equal(to_soa(d_b.cpu().numpy()), want, f"aos contracted {scene}/{scheme} k={k} {nx}x{ny}")
+        # the reference-named whole-lattice sweep
+        nx, ny = 230, 11
+        f = random_state(rng, nx, ny, dtype)
+        want = oracle_steps(ONE_STEP[(scene, scheme)], f, 1, 0.9, dtype)
+        d_f = torch.from_numpy(to_aos(f)).cuda()
+        d_b = torch.full_like(d_f, float("nan"))
+        if scene == "shear":
+            getattr(ops, ONE_STEP[(scene, scheme)])(d_f, d_b, nx, ny, 0.9)
+        else:
+            getattr(ops, ONE_STEP[(scene, scheme)])(d_f, d_b, nx, ny, 0.9, RHO, U)
+        assert_bits_equal(to_soa(d_b.cpu().numpy()), want, f"aos contracted {scene}/{scheme} one step")
+    assert ops.get_arithmetic() == "unrolled" and orc.get_arithmetic() == "unrolled"

@@ -53,3 +53,32 @@ def test_product_package_does_not_use_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 for needle in ("import oracle", "from oracle", "liblbm_oracle", "lbm_oracle", "oracle/"):
                     assert needle not in text, f"{top}/{fn} refers to the oracle ({needle!r})"
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    """Every kernel keeps its rings and temporaries in registers and LDS: a spill to scratch memory
+    (private segment) costs a multi-step sweep half its rate, so the code object of the built
+    library is read back and every kernel's private segment must be empty and its register count
+    must allow two wavefronts per SIMD (256 VGPRs)."""
+    import shutil
+    import subprocess
+
+    import pytest
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) or shutil.which(os.path.basename(t)) for t in tools):
+        pytest.skip("LLVM binary tools of the ROCm installation not found")
+    objcopy, bundler, readelf = tools
+    fat, dev = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    subprocess.check_call([objcopy, f"--dump-section=.hip_fatbin={fat}", capi.LIB_PATH, str(tmp_path / "rest.so")])
+    subprocess.check_call([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--input={fat}", f"--output={dev}"])
+    notes = subprocess.check_output([readelf, "--notes", dev], text=True)
+    kernels = re.findall(r"\.name:\s+(_Z\S+|\w+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s+(\d+)", notes)
+    scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+    vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", notes)]
+    assert len(scratch) > 300 and len(vgprs) == len(scratch), "kernel metadata not found in the code object"
+    assert max(scratch) == 0, f"{sum(1 for x in scratch if x)} kernel(s) spill to scratch memory"
+    assert max(vgprs) <= 256
+    assert any("k_fused" in name for name, _ in kernels)

@@ -159,8 +159,11 @@ def test_limits():
         ops.pull_periodic_fused(even, torch.zeros_like(even), 0.7, 0, 6, True, 9)
     with ops.layout("aos"):
         a = torch.zeros((6, 64, 9), dtype=torch.float32, device="cuda")
+        assert ops.fused_max_steps(a) == 8
+        a = torch.zeros((6, 67, 9), dtype=torch.float32, device="cuda")
+        assert ops.fused_max_steps(a) == 1
         with pytest.raises(capi.LbmError, match="unsupported"):
-            ops.pull_periodic_no_mpi(a, torch.zeros_like(a), 64, 6, 0.7)
+            ops.pull_periodic_no_mpi(a, torch.zeros_like(a), 67, 6, 0.7)
     # a run is cut into equal launches of at most eight steps
     big = torch.zeros((9, 4096, 4096), dtype=torch.float32, device="cuda")
     assert ops.plan_steps(big, 4096, 100) <= 8
