@@ -32,12 +32,19 @@ run under MPI, main.cpp:317-319), one time step per exchange:
          (main.cpp:238-261) and is not a correct exchange for it; this one is bit-identical to the
          single-device push run.
 
-For one node of GPUs the y-slab path (lbm_amd.slab, and `main -gpus N`) is the supported fast
-decomposition: it keeps rows whole, so its sweeps are the vectorised multi-step kernels with
-ghost rows as deep as a block of steps.  This module is the drop-in for the reference's
-inner / outer operators on lattices cut in both directions; it stays at one step per exchange
-(blocks of k steps would need k-deep halos in x as well, which the row-oriented multi-step
-kernels do not take).
+Blocks of several steps per exchange (`halo` > 1, the default wherever the multi-step sweeps take
+the block): the local array carries a frame of G nodes on every side, [9][ny+2G][nx+2G] (one more
+column on the right where that makes the row length even), holding plain copies of the
+neighbours' outermost owned nodes, all nine populations.  One launch of the multi-step periodic
+sweep advances rows [G, G+ny) of that array k <= G steps as if it were a lattice nx+2G wide that
+wraps in x: what the wrap gets wrong travels one column per step and stays inside the frame, the
+owned nodes come out exactly as on a single device.  Then the frame is refilled -- columns over
+the owned rows first, then rows over the full width, so the corners ride along: four messages per
+block of k steps, pull and push alike.  The exchange follows the sweep on the same stream (the
+column phase needs every owned row, so there is no interior to overlap it with).
+
+For one node of GPUs the y-slab path (lbm_amd.slab, and `main -gpus N`) stays the fast
+decomposition: it keeps rows whole and overlaps its exchange with the interior sweep.
 
 Kernels are reached through a small backend object so that the schedule can be exercised on CPU
 ranks in tests; the default backend is the HIP operator layer and refuses CPU tensors.
@@ -83,8 +90,15 @@ class HipCartBackend:
         from . import ops
         self.ops = ops
 
-    def init_shearwave(self, f, rho, u, y_below, y_glob):
-        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=1)
+    def init_shearwave(self, f, rho, u, y_below, y_glob, halo=1):
+        self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=halo)
+
+    def plan_steps(self, f, rows, remaining):
+        """Steps one launch should take on rows of f's length (1: one-step sweeps only)."""
+        return self.ops.plan_steps(f, rows, remaining)
+
+    def periodic_fused(self, scheme, f, buf, om, y_lo, y_hi, k):
+        getattr(self.ops, f"{scheme}_periodic_fused")(f, buf, om, y_lo, y_hi, False, k)
 
     def pull_inner(self, f, buf, om, LX, LY, HX, HY):
         self.ops.pull_periodic_inner(f, buf, om, LX, LY, HX, HY)
@@ -103,11 +117,16 @@ class HipCartBackend:
 
 
 class CartSimulation:
-    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull or push scheme."""
+    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull or push scheme.
+
+    halo: frame depth = steps per exchange.  None (default) asks the library, 1 is the reference's
+    scheme (inner sweep || exchange, outer ring), > 1 runs blocks of up to that many steps in one
+    launch of the multi-step periodic sweep."""
 
     def __init__(self, nx_glob: int, ny_glob: int, dtype: torch.dtype = torch.float32, omega: float = 0.5,
                  rho: float = 1.0, u: float = 0.1, device="cuda:0", backend=None,
-                 dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True, scheme: str = "pull"):
+                 dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True, scheme: str = "pull",
+                 halo: Optional[int] = None):
         if scheme not in ("pull", "push"):
             raise ValueError(f"unknown scheme {scheme!r}")
         self.scheme = scheme
@@ -137,22 +156,62 @@ class CartSimulation:
                              "ranks leaves blocks of fewer than 2 x 2 nodes")
         self.omega = float(omega)
         self.t = 0
-        self.f = torch.zeros((9, self.ny + 2, self.nx + 2), dtype=dtype, device=self.device)
+        # Frame depth G.  halo=None: what the library plans per launch for the smallest block of the
+        # grid (every rank must arrive at the same answer), as long as that block has G owned rows
+        # and columns to send; 1 = the reference's scheme, one step per exchange.
+        nx_min, ny_min = self.nx_glob // self.dims[0], self.ny_glob // self.dims[1]
+        if halo is None:
+            halo = 1
+            if hasattr(self.backend, "plan_steps") and hasattr(self.backend, "periodic_fused"):
+                halo = self._planned_depth(dtype, nx_min, ny_min)
+        self.G = G = int(halo)
+        if G < 1:
+            raise ValueError(f"halo depth must be positive (got {halo})")
+        if G > 1 and (nx_min < G or ny_min < G):
+            raise ValueError(f"halo depth {G} needs blocks of at least {G} x {G} nodes")
+        self.deep = G > 1
+        # deep frames: rows of an even length whatever nx is (the fp32 multi-step sweeps take two
+        # nodes per lane); the extra column sits beyond the right frame and is never exchanged
+        self.W = self.nx + 2 * G + ((self.nx + 2 * G) % 2 if self.deep else 0)
+        self.f = torch.zeros((9, self.ny + 2 * G, self.W), dtype=dtype, device=self.device)
         self.buf = torch.zeros_like(self.f)
-        self.backend.init_shearwave(self.f, float(rho), float(u), self.y_below, self.ny_glob)
+        if self.deep:
+            # the wave is x-invariant: initialising whole rows fills the frame columns correctly
+            self.backend.init_shearwave(self.f, float(rho), float(u), self.y_below, self.ny_glob, halo=G)
+            self.buf.copy_(self.f)      # defined values everywhere a sweep may read
+        else:
+            self.backend.init_shearwave(self.f, float(rho), float(u), self.y_below, self.ny_glob)
         self._idx = {name: torch.tensor(ch, dtype=torch.long, device=self.device)
                      for name, ch in (("R", RIGHT_MOVERS), ("L", LEFT_MOVERS), ("U", UP_MOVERS), ("D", DOWN_MOVERS))}
         # pull: owned height / full width; push: full height (corner travellers) / owned width
         col_len, row_len = (self.ny, self.nx + 2) if scheme == "pull" else (self.ny + 2, self.nx)
-        self._col = [torch.empty((3, col_len), dtype=dtype, device=self.device) for _ in range(2)]
-        self._row = [torch.empty((3, row_len), dtype=dtype, device=self.device) for _ in range(2)]
+        if self.deep:
+            self._col = [torch.empty((9, self.ny, G), dtype=dtype, device=self.device) for _ in range(2)]
+            self._row = [torch.empty((9, G, self.W), dtype=dtype, device=self.device) for _ in range(2)]
+        else:
+            self._col = [torch.empty((3, col_len), dtype=dtype, device=self.device) for _ in range(2)]
+            self._row = [torch.empty((3, row_len), dtype=dtype, device=self.device) for _ in range(2)]
         self._vel: Optional[torch.Tensor] = None
         # a second stream only where the exchange is stream-ordered (RCCL, or copies within the
         # rank); under the rehearsal transport the exchange blocks the host anyway
         self.overlap = bool(overlap) and self.cuda and (self.world == 1 or self.stream_ordered)
         # the device's one communication stream, shared with the y-slab path: see slab._edge_stream
         # for why every object must not take a fresh stream
-        self._comm = _edge_stream(self.device) if self.overlap else None
+        self._comm = _edge_stream(self.device) if (self.overlap and not self.deep) else None
+        if self.deep:
+            self.overlap = False
+            self._exchange_deep()       # ghost rows of the initial state (and the frame columns again)
+
+    def _planned_depth(self, dtype, nx_min: int, ny_min: int) -> int:
+        """Steps per launch for the smallest block of the grid, 1 if the multi-step sweeps do not
+        take it.  Every block of the grid is at most one node wider; the row length is made even."""
+        depth = 1
+        for _ in range(2):      # the row length depends on the depth: settle in two rounds
+            w = nx_min + 2 * depth
+            probe = torch.empty((9, 1, w + w % 2), dtype=dtype, device=self.device)
+            planned = int(self.backend.plan_steps(probe, ny_min, 1 << 30))
+            depth = max(1, min(planned, nx_min, ny_min))
+        return depth
 
     # ---- neighbours ---------------------------------------------------------------------------
     def _rank_at(self, cx: int, cy: int) -> int:
@@ -207,6 +266,30 @@ class CartSimulation:
         f[U, 0, :] = self._row[0]
         f[D, ny + 1, :] = self._row[1]
 
+    def _exchange_deep(self) -> None:
+        """Refill the frame of f from the neighbours' owned nodes, all nine populations: columns
+        over the owned rows, then rows over the full width (the corners ride along)."""
+        f, nx, ny, G = self.f, self.nx, self.ny, self.G
+        cx, cy = self.coords
+        to_right = f[:, G:G + ny, nx:nx + G].contiguous()        # my last G owned columns
+        to_left = f[:, G:G + ny, G:2 * G].contiguous()           # my first G owned columns
+        self._swap(to_right, to_left, self._col[0], self._col[1], self._rank_at(cx + 1, cy), self._rank_at(cx - 1, cy))
+        f[:, G:G + ny, 0:G] = self._col[0]
+        f[:, G:G + ny, nx + G:nx + 2 * G] = self._col[1]
+        to_up = f[:, ny:ny + G, :].contiguous()                  # my highest G owned rows
+        to_down = f[:, G:2 * G, :].contiguous()                  # my lowest G owned rows
+        self._swap(to_up, to_down, self._row[0], self._row[1], self._rank_at(cx, cy + 1), self._rank_at(cx, cy - 1))
+        f[:, 0:G, :] = self._row[0]
+        f[:, ny + G:ny + 2 * G, :] = self._row[1]
+
+    def _block_deep(self, k: int) -> None:
+        """k <= G time steps of the block in one launch, then the frame of the new state."""
+        G = self.G
+        self.backend.periodic_fused(self.scheme, self.f, self.buf, self.omega, G, G + self.ny, k)
+        self.f, self.buf = self.buf, self.f
+        self._exchange_deep()
+        self.t += k
+
     def _return_outflow(self) -> None:
         """Push scheme: what the last step scattered into the halo ring of f goes to the neighbours'
         edge nodes (the reverse of _exchange).  Columns over the full height first -- the entries in
@@ -250,6 +333,15 @@ class CartSimulation:
 
     # ---- one time step (main.cpp:217-398) ------------------------------------------------------
     def step(self, nsteps: int = 1) -> None:
+        if self.deep:
+            # the fewest blocks of at most G steps, as equal as possible
+            left = int(nsteps)
+            while left > 0:
+                blocks = -(-left // self.G)
+                k = -(-left // blocks)
+                self._block_deep(k)
+                left -= k
+            return
         for _ in range(int(nsteps)):
             if self.scheme == "push":
                 self._step_push()
@@ -275,10 +367,11 @@ class CartSimulation:
     def velocities(self) -> torch.Tensor:
         """ux, uy of the owned nodes: [2, ny, nx]."""
         self._complete()
+        G = self.G
         if self._vel is None:
-            self._vel = torch.empty((2, self.ny, self.nx + 2), dtype=self.f.dtype, device=self.device)
-        self.backend.compute_velocities(self._vel, self.f, 1, self.ny + 1)
-        return self._vel[:, :, 1:self.nx + 1]
+            self._vel = torch.empty((2, self.ny, self.f.shape[2]), dtype=self.f.dtype, device=self.device)
+        self.backend.compute_velocities(self._vel, self.f, G, self.ny + G)
+        return self._vel[:, :, G:self.nx + G]
 
     def max_velocity(self) -> float:
         """Global max |u| (io.cpp:184-216: float square root, NaN never wins, MPI_Reduce(MAX))."""
@@ -295,7 +388,8 @@ class CartSimulation:
     def interior(self) -> torch.Tensor:
         """The owned nodes without the halo: [9, ny, nx] (a view)."""
         self._complete()
-        return self.f[:, 1:self.ny + 1, 1:self.nx + 1]
+        G = self.G
+        return self.f[:, G:self.ny + G, G:self.nx + G]
 
     def gather_populations(self) -> Optional[torch.Tensor]:
         """Rank 0 gets the global [9, NY, NX] populations (for tests / small outputs)."""

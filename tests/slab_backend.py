@@ -87,16 +87,10 @@ class OracleBackend:
         vel.numpy()[:] = orc.compute_velocities(f.numpy(), y_lo, y_hi)
 
 
-class OracleCartBackend:
-    """CPU stand-in for the block kernels of lbm_amd.cart (halo ring of one node, inner / outer
-    sweeps), built on the oracle."""
-
-    def init_shearwave(self, f, rho, u, y_below, y_glob):
-        a = f.numpy()
-        interior = np.ascontiguousarray(a[:, 1:a.shape[1] - 1])
-        t = a.dtype.type
-        orc.init_shearwave(interior, t(rho), t(u), y_below, y_glob)
-        a[:, 1:a.shape[1] - 1] = interior
+class OracleCartBackend(OracleBackend):
+    """CPU stand-in for the block kernels of lbm_amd.cart, built on the oracle: inner / outer sweeps
+    for the halo ring of one node, and the multi-step sweep of the slab stand-in for deep frames
+    (fused_depth > 1 makes CartSimulation(halo=None) choose them)."""
 
     def pull_inner(self, f, buf, om, LX, LY, HX, HY):
         a = f.numpy()

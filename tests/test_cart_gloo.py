@@ -82,6 +82,81 @@ def test_blocks_reproduce_the_single_domain_run(world, dims):
         assert vmax == float(orc.max_velocity(want))
 
 
+# blocks of several steps per exchange: (dtype, nx, ny, steps, omega, frame depth); the smallest block
+# of every grid below has at least `depth` owned rows and columns
+DEEP_CASES = [
+    ("float32", 24, 18, 25, 0.8, 3),     # odd local row lengths get the extra column
+    ("float64", 17, 19, 30, 1.3, 4),
+    ("float32", 16, 12, 13, 1.9, 2),
+    ("float64", 20, 21, 16, 0.6, None),  # depth chosen by the backend's plan (5)
+]
+
+
+def _worker_deep(rank, world, dims, store_path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from lbm_amd.cart import CartSimulation
+    from slab_backend import OracleCartBackend
+    dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
+    results = {}
+    try:
+        for (tdt, nx, ny, steps, omega, depth) in DEEP_CASES:
+            for scheme in ("pull", "push"):
+                backend = OracleCartBackend()
+                backend.fused_depth = 5
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cpu",
+                                     backend=backend, dims=dims, scheme=scheme, halo=depth)
+                assert sim.deep and sim.G == (depth or 5) and sim.f.shape[2] % 2 == 0
+                vmax0 = sim.max_velocity()
+                sim.step(steps)
+                assert sim.t == steps
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[(tdt, nx, ny, steps, omega, depth, scheme)] = (full.numpy().copy(), vmax0, vmax)
+        if rank == 0:
+            torch.save(results, out_path)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, None), (4, None), (3, (1, 3)), (6, None)])
+def test_deep_frames_reproduce_the_single_domain_run(world, dims):
+    """Blocks of up to `depth` steps per exchange on frames `depth` nodes deep, all nine populations,
+    columns then rows: bit for bit the single-domain run, pull and push."""
+    from oracle import oracle as orc
+    with tempfile.TemporaryDirectory() as tmp:
+        store, out = os.path.join(tmp, "store"), os.path.join(tmp, "out.pt")
+        mp.spawn(_worker_deep, args=(world, dims, store, out), nprocs=world, join=True)
+        results = torch.load(out, weights_only=False)
+    assert len(results) == 2 * len(DEEP_CASES)
+    for (tdt, nx, ny, steps, omega, depth, scheme), (full, vmax0, vmax) in results.items():
+        dtype = getattr(np, tdt)
+        want, _ = orc.run("shear", scheme, nx, ny, steps, omega, dtype)
+        bits = np.uint32 if dtype == np.float32 else np.uint64
+        assert (full.view(bits) == want.view(bits)).all(), (world, dims, tdt, nx, ny, depth, scheme)
+        start = orc.alloc(nx, ny, dtype)
+        orc.init_shearwave(start, dtype(1.0), dtype(0.1))
+        assert vmax0 == float(orc.max_velocity(start))
+        assert vmax == float(orc.max_velocity(want))
+
+
+def test_deep_frames_limits():
+    from lbm_amd.cart import CartSimulation
+    from slab_backend import OracleCartBackend
+    with pytest.raises(ValueError, match="halo depth"):
+        CartSimulation(9, 6, device="cpu", backend=OracleCartBackend(), halo=7)     # more than the block has rows
+    with pytest.raises(ValueError, match="halo depth"):
+        CartSimulation(9, 6, device="cpu", backend=OracleCartBackend(), halo=0)
+    b = OracleCartBackend()
+    b.fused_depth = 8
+    sim = CartSimulation(9, 6, device="cpu", backend=b)      # planned depth is capped by the block: 6 rows
+    assert sim.G == 6 and sim.deep
+
+
 def test_single_rank_wraps_onto_itself():
     """No process group at all: every neighbour is the rank itself."""
     from oracle import oracle as orc

@@ -1,7 +1,7 @@
 """The 2-D Cartesian decomposition (lbm_amd.cart) on the GPU: the HIP inner / outer sweeps on a
-block with a halo ring, the packing and the second stream -- first with the rank as its own
-neighbour in both directions, then four and six ranks sharing cuda:0 over gloo (RCCL refuses
-several ranks on one GPU)."""
+block with a halo ring, the packing and the second stream, and the multi-step sweeps on blocks
+with deep frames -- first with the rank as its own neighbour in both directions, then four and
+six ranks sharing cuda:0 over gloo (RCCL refuses several ranks on one GPU)."""
 import faulthandler
 import os
 import sys
@@ -24,11 +24,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("scheme", ["pull", "push"])
-def test_one_rank_equals_the_oracle(dtype, overlap, scheme):
+@pytest.mark.parametrize("halo", [1, None, 3])
+def test_one_rank_equals_the_oracle(dtype, overlap, scheme, halo):
+    """halo 1: the reference's scheme (inner sweep || exchange, outer ring); None / 3: blocks of
+    several steps per exchange on deep frames (the depth the library plans, or three)."""
     from lbm_amd.cart import CartSimulation
     npdt = np.float32 if dtype == torch.float32 else np.float64
     for nx, ny, steps, omega in ((64, 48, 40, 0.8), (131, 37, 25, 1.4), (2, 2, 9, 1.0), (1024, 300, 12, 0.5)):
-        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap, scheme=scheme)
+        if halo == 3 and min(nx, ny) < 3:
+            with pytest.raises(ValueError):
+                CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap, scheme=scheme, halo=halo)
+            continue
+        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, overlap=overlap, scheme=scheme, halo=halo)
+        assert sim.deep == (halo != 1 and sim.G > 1) and (halo is None or sim.G == halo)
+        if halo is None and min(nx, ny) >= 8:
+            assert sim.deep, "the planned depth should select deep frames on blocks this large"
         sim.step(steps)
         want, _ = orc.run("shear", scheme, nx, ny, steps, omega, npdt)
         assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 {scheme} {nx}x{ny}")
@@ -50,13 +60,14 @@ def _worker(rank, world, store_path, out_path):
     try:
         for case in CASES:
             tdt, nx, ny, steps, omega = case
-            for scheme in ("pull", "push"):
-                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0", scheme=scheme)
+            for scheme, halo in (("pull", 1), ("push", 1), ("pull", None), ("push", None), ("pull", 4)):
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0", scheme=scheme,
+                                     halo=halo)
                 sim.step(steps)
                 vmax = sim.max_velocity()
                 full = sim.gather_populations()
                 if rank == 0:
-                    results[case + (scheme,)] = (full.cpu().numpy(), vmax, sim.dims)
+                    results[case + (scheme, halo)] = (full.cpu().numpy(), vmax, sim.dims, sim.G)
         if rank == 0:
             torch.save(results, out_path)
     finally:
@@ -70,8 +81,10 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world, ranks_shar
         out = os.path.join(tmp, "out.pt")
         mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), out), nprocs=world, join=True)
         results = torch.load(out, weights_only=False)
-    for (tdt, nx, ny, steps, omega, scheme), (full, vmax, dims) in results.items():
+    assert len(results) == 5 * len(CASES)
+    for (tdt, nx, ny, steps, omega, scheme, halo), (full, vmax, dims, depth) in results.items():
         assert dims == ((2, 2) if world == 4 else (3, 2))
+        assert depth == halo if halo is not None else depth > 1
         want, _ = orc.run("shear", scheme, nx, ny, steps, omega, getattr(np, tdt))
-        assert_bits_equal(full, want, f"cart {dims} {scheme} {tdt} {nx}x{ny}")
+        assert_bits_equal(full, want, f"cart {dims} {scheme} {tdt} {nx}x{ny} frame depth {depth}")
         assert vmax == float(orc.max_velocity(want))
