@@ -126,10 +126,14 @@ class CartSimulation:
     def __init__(self, nx_glob: int, ny_glob: int, dtype: torch.dtype = torch.float32, omega: float = 0.5,
                  rho: float = 1.0, u: float = 0.1, device="cuda:0", backend=None,
                  dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True, scheme: str = "pull",
-                 halo: Optional[int] = None):
+                 halo: Optional[int] = None, p2p_to_self: bool = False):
         if scheme not in ("pull", "push"):
             raise ValueError(f"unknown scheme {scheme!r}")
         self.scheme = scheme
+        # p2p_to_self: a rank that is its own neighbour along an axis still routes its halos through
+        # the process group's send/recv (to itself) instead of local copies -- exercises the real
+        # transport, e.g. RCCL on a one-GPU machine
+        self.p2p_to_self = bool(p2p_to_self)
         self._outflow_pending = False   # push: the halo ring of f holds what the last step pushed out of the block
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -142,6 +146,8 @@ class CartSimulation:
             self.stream_ordered = self.cuda and dist.get_backend(group) == "nccl"
         else:
             self.world, self.rank, self.stream_ordered = 1, 0, False
+            if self.p2p_to_self:
+                raise RuntimeError("p2p_to_self needs an initialised process group")
         self.dims = tuple(int(d) for d in dims) if dims is not None else dims_create(self.world)
         if len(self.dims) != 2 or self.dims[0] * self.dims[1] != self.world:
             raise ValueError(f"dims {self.dims} do not multiply to the world size {self.world}")
@@ -223,7 +229,7 @@ class CartSimulation:
     def _swap(self, send_hi, send_lo, recv_lo, recv_hi, hi_rank: int, lo_rank: int) -> None:
         """send_hi goes to the neighbour at the higher coordinate and arrives in its recv_lo;
         send_lo goes to the lower neighbour and arrives in its recv_hi."""
-        if hi_rank == self.rank:            # one rank along this axis: the lattice wraps onto itself
+        if hi_rank == self.rank and not self.p2p_to_self:   # one rank along this axis: the lattice wraps onto itself
             recv_lo.copy_(send_hi)
             recv_hi.copy_(send_lo)
             return

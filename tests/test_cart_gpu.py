@@ -88,3 +88,42 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world, ranks_shar
         want, _ = orc.run("shear", scheme, nx, ny, steps, omega, getattr(np, tdt))
         assert_bits_equal(full, want, f"cart {dims} {scheme} {tdt} {nx}x{ny} frame depth {depth}")
         assert vmax == float(orc.max_velocity(want))
+
+
+def _worker_rccl_self(rank, world, port, out_dir):
+    """World of one over RCCL: along both axes the neighbour is this rank itself, and every halo goes
+    through the grouped send/recv that a multi-GPU run uses, on the stream the sweeps run on."""
+    sys.path.insert(0, ROOT)
+    faulthandler.dump_traceback_later(100, exit=True)
+    from lbm_amd.cart import CartSimulation
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ok = True
+    try:
+        for scheme, tdt, ndt, nx, ny, halo in (("pull", torch.float32, np.float32, 1024, 300, 1),
+                                               ("push", torch.float32, np.float32, 1024, 300, 1),
+                                               ("pull", torch.float32, np.float32, 1024, 300, None),
+                                               ("push", torch.float64, np.float64, 515, 130, None),
+                                               ("pull", torch.float64, np.float64, 515, 130, 3),
+                                               ("push", torch.float32, np.float32, 1030, 64, 6)):
+            steps, omega = 19, 0.7
+            sim = CartSimulation(nx, ny, dtype=tdt, omega=omega, device="cuda:0", scheme=scheme, halo=halo,
+                                 p2p_to_self=True)
+            assert sim.stream_ordered and sim.deep == (halo != 1)
+            sim.step(steps)
+            vmax = sim.max_velocity()
+            want, _ = orc.run("shear", scheme, nx, ny, steps, omega, ndt)
+            same = np.array_equal(sim.interior().cpu().numpy().view(np.uint8), want.view(np.uint8))
+            ok = ok and same and vmax == float(orc.max_velocity(want))
+        with open(os.path.join(out_dir, "result.txt"), "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_with_self_as_every_neighbour():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_rccl_self, args=(1, 29547, tmp), nprocs=1, join=True)
+        assert open(os.path.join(tmp, "result.txt")).read() == "ok"
