@@ -71,6 +71,10 @@
 #ifndef LBM_FUSED_PREFETCH_F32
 #define LBM_FUSED_PREFETCH_F32 1
 #endif
+// Fewest wavefronts per SIMD the register allocation must allow (2: up to 256 VGPRs).
+#ifndef LBM_FUSED_MIN_WAVES
+#define LBM_FUSED_MIN_WAVES 2
+#endif
 // Wavefronts per workgroup (0 = the built-in choice, fused_group_waves()).
 #ifndef LBM_FUSED_GROUP_WAVES
 #define LBM_FUSED_GROUP_WAVES 0
@@ -180,6 +184,15 @@ constexpr int fused_max_waves_per_simd()
     constexpr int lds = fused_lds_bytes_per_wave<T, V, K, PUSH, LID, AOS, ARITH>();
     constexpr int per_simd = lds == 0 ? 8 : (160 * 1024 / (lds == 0 ? 1 : lds) + 3) / 4;
     return per_simd < 2 ? 2 : (per_simd > 8 ? 8 : per_simd);
+}
+
+// Fewest wavefronts per SIMD the register allocation must leave room for: LBM_FUSED_MIN_WAVES where
+// the LDS lets that many be resident at all.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_min_waves_per_simd()
+{
+    constexpr int most = fused_max_waves_per_simd<T, V, K, PUSH, LID, AOS, ARITH>();
+    return LBM_FUSED_MIN_WAVES < most ? LBM_FUSED_MIN_WAVES : most;
 }
 
 // The LDS of a workgroup, carved up by fused_body.
@@ -803,7 +816,7 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
 // 236 -> 223 GLUPS).
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS = false, int ARITH = kArithUnrolled, bool NARROW = false>
 __global__ void __launch_bounds__(kWave * kFusedMaxGroupWaves)
-    __attribute__((amdgpu_waves_per_eu(2, fused_max_waves_per_simd<T, V, K, PUSH, LID, AOS, ARITH>())))
+    __attribute__((amdgpu_waves_per_eu(fused_min_waves_per_simd<T, V, K, PUSH, LID, AOS, ARITH>(), fused_max_waves_per_simd<T, V, K, PUSH, LID, AOS, ARITH>())))
 k_fused(const T *__restrict__ f, T *__restrict__ buf, const FusedGeom g, const T om, const T df_lid)
 {
     static_assert(ARITH != kArithRolled || (!LID && !AOS), "the rolled arithmetic exists for periodic [9][NY][NX] sweeps only");
