@@ -1,4 +1,5 @@
-"""2-D Cartesian decomposition of the periodic shear-wave lattice over ranks (torch.distributed).
+"""2-D Cartesian decomposition of the lattice over ranks (torch.distributed): the periodic shear
+wave as the reference decomposes it, and the lid-driven cavity, which the reference does not.
 
 The reference's MPI path (src/main.cpp:92-401): ranks form a periodic dims[0] x dims[1] grid, every
 rank owns an nx x ny block of the lattice inside a local array with a halo of one node on every
@@ -42,6 +43,10 @@ owned nodes come out exactly as on a single device.  Then the frame is refilled 
 the owned rows first, then rows over the full width, so the corners ride along: four messages per
 block of k steps, pull and push alike.  The exchange follows the sweep on the same stream (the
 column phase needs every owned row, so there is no interior to overlap it with).
+
+The lid-driven cavity (scene "lid") runs on the same frames with the multi-step cavity sweeps:
+blocks carry a frame only towards neighbours, a block at a wall ends at its array's edge, where
+the sweeps apply the wall (see CartSimulation).
 
 For one node of GPUs the y-slab path (lbm_amd.slab, and `main -gpus N`) stays the fast
 decomposition: it keeps rows whole and overlaps its exchange with the interior sweep.
@@ -93,12 +98,18 @@ class HipCartBackend:
     def init_shearwave(self, f, rho, u, y_below, y_glob, halo=1):
         self.ops.init_shearwave(f, rho, u, y_below, y_glob, halo=halo)
 
-    def plan_steps(self, f, rows, remaining):
+    def init_rest(self, f, rho):
+        self.ops.init_rest(f, rho)
+
+    def plan_steps(self, f, rows, remaining, lid=False):
         """Steps one launch should take on rows of f's length (1: one-step sweeps only)."""
-        return self.ops.plan_steps(f, rows, remaining)
+        return self.ops.plan_steps(f, rows, remaining, lid=lid)
 
     def periodic_fused(self, scheme, f, buf, om, y_lo, y_hi, k):
         getattr(self.ops, f"{scheme}_periodic_fused")(f, buf, om, y_lo, y_hi, False, k)
+
+    def lid_fused(self, scheme, f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob, k):
+        getattr(self.ops, f"{scheme}_lid_fused")(f, buf, om, rho, u, y_lo, y_hi, y_goff, ny_glob, k)
 
     def pull_inner(self, f, buf, om, LX, LY, HX, HY):
         self.ops.pull_periodic_inner(f, buf, om, LX, LY, HX, HY)
@@ -117,19 +128,30 @@ class HipCartBackend:
 
 
 class CartSimulation:
-    """Periodic shear-wave decay on a dims[0] x dims[1] grid of ranks, pull or push scheme.
+    """Shear-wave decay (periodic) or the lid-driven cavity on a dims[0] x dims[1] grid of ranks, pull
+    or push scheme.
 
     halo: frame depth = steps per exchange.  None (default) asks the library, 1 is the reference's
-    scheme (inner sweep || exchange, outer ring), > 1 runs blocks of up to that many steps in one
-    launch of the multi-step periodic sweep."""
+    scheme (inner sweep || exchange, outer ring; periodic scene only), > 1 runs blocks of up to that
+    many steps in one launch of the multi-step sweep.
+
+    scene "lid": the cavity of pull-push.cpp:432-531 cut in both directions, which the reference
+    refuses to run under MPI (main.cpp:317-319).  Blocks carry a frame only towards neighbours: a
+    block at a wall starts (ends) at its array's first (last) column or row, which is where the
+    cavity sweeps apply the wall; towards a neighbour the sweeps see a wall at the end of the frame
+    that is not there, and what that gets wrong stays inside the frame like the x wrap of the
+    periodic scene.  Always on frames (any depth >= 1), never with the halo ring."""
 
     def __init__(self, nx_glob: int, ny_glob: int, dtype: torch.dtype = torch.float32, omega: float = 0.5,
                  rho: float = 1.0, u: float = 0.1, device="cuda:0", backend=None,
                  dims: Optional[Sequence[int]] = None, group=None, overlap: bool = True, scheme: str = "pull",
-                 halo: Optional[int] = None, p2p_to_self: bool = False):
+                 halo: Optional[int] = None, p2p_to_self: bool = False, scene: str = "shear"):
         if scheme not in ("pull", "push"):
             raise ValueError(f"unknown scheme {scheme!r}")
-        self.scheme = scheme
+        if scene not in ("shear", "lid"):
+            raise ValueError(f"unknown scene {scene!r}")
+        self.scheme, self.scene = scheme, scene
+        self.periodic = scene == "shear"
         # p2p_to_self: a rank that is its own neighbour along an axis still routes its halos through
         # the process group's send/recv (to itself) instead of local copies -- exercises the real
         # transport, e.g. RCCL on a one-GPU machine
@@ -161,7 +183,12 @@ class CartSimulation:
             raise ValueError(f"a {self.nx_glob} x {self.ny_glob} lattice on a {self.dims[0]} x {self.dims[1]} grid of "
                              "ranks leaves blocks of fewer than 2 x 2 nodes")
         self.omega = float(omega)
+        self.rho, self.u = float(rho), float(u)
         self.t = 0
+        self._vel: Optional[torch.Tensor] = None
+        if not self.periodic:
+            self._setup_cavity(dtype, halo)
+            return
         # Frame depth G.  halo=None: what the library plans per launch for the smallest block of the
         # grid (every rank must arrive at the same answer), as long as that block has G owned rows
         # and columns to send; 1 = the reference's scheme, one step per exchange.
@@ -176,6 +203,7 @@ class CartSimulation:
         if G > 1 and (nx_min < G or ny_min < G):
             raise ValueError(f"halo depth {G} needs blocks of at least {G} x {G} nodes")
         self.deep = G > 1
+        self.x0 = self.y0 = G       # first owned column / row of the local arrays
         # deep frames: rows of an even length whatever nx is (the fp32 multi-step sweeps take two
         # nodes per lane); the extra column sits beyond the right frame and is never exchanged
         self.W = self.nx + 2 * G + ((self.nx + 2 * G) % 2 if self.deep else 0)
@@ -197,7 +225,6 @@ class CartSimulation:
         else:
             self._col = [torch.empty((3, col_len), dtype=dtype, device=self.device) for _ in range(2)]
             self._row = [torch.empty((3, row_len), dtype=dtype, device=self.device) for _ in range(2)]
-        self._vel: Optional[torch.Tensor] = None
         # a second stream only where the exchange is stream-ordered (RCCL, or copies within the
         # rank); under the rehearsal transport the exchange blocks the host anyway
         self.overlap = bool(overlap) and self.cuda and (self.world == 1 or self.stream_ordered)
@@ -208,16 +235,101 @@ class CartSimulation:
             self.overlap = False
             self._exchange_deep()       # ghost rows of the initial state (and the frame columns again)
 
-    def _planned_depth(self, dtype, nx_min: int, ny_min: int) -> int:
+    def _planned_depth(self, dtype, nx_min: int, ny_min: int, lid: bool = False) -> int:
         """Steps per launch for the smallest block of the grid, 1 if the multi-step sweeps do not
         take it.  Every block of the grid is at most one node wider; the row length is made even."""
         depth = 1
         for _ in range(2):      # the row length depends on the depth: settle in two rounds
             w = nx_min + 2 * depth
             probe = torch.empty((9, 1, w + w % 2), dtype=dtype, device=self.device)
-            planned = int(self.backend.plan_steps(probe, ny_min, 1 << 30))
+            planned = int(self.backend.plan_steps(probe, ny_min, 1 << 30, lid) if lid
+                          else self.backend.plan_steps(probe, ny_min, 1 << 30))
             depth = max(1, min(planned, nx_min, ny_min))
         return depth
+
+    # ---- lid-driven cavity ----------------------------------------------------------------------
+    def _setup_cavity(self, dtype, halo: Optional[int]) -> None:
+        b = self.backend
+        if not all(hasattr(b, name) for name in ("lid_fused", "plan_steps", "init_rest")):
+            raise RuntimeError("the backend has no multi-step cavity sweep")
+        cx, cy = self.coords
+        # neighbours; None = wall
+        self.left = self._rank_at(cx - 1, cy) if cx > 0 else None
+        self.right = self._rank_at(cx + 1, cy) if cx < self.dims[0] - 1 else None
+        self.lower = self._rank_at(cx, cy - 1) if cy > 0 else None
+        self.upper = self._rank_at(cx, cy + 1) if cy < self.dims[1] - 1 else None
+        nx_min, ny_min = self.nx_glob // self.dims[0], self.ny_glob // self.dims[1]
+        if halo is None:
+            halo = self._planned_depth(dtype, nx_min, ny_min, lid=True)
+        self.G = G = int(halo)
+        if G < 1:
+            raise ValueError(f"halo depth must be positive (got {halo})")
+        if nx_min < G or ny_min < G:
+            raise ValueError(f"halo depth {G} needs blocks of at least {G} x {G} nodes")
+        self.deep = True
+        fl, fr = (G if self.left is not None else 0), (G if self.right is not None else 0)
+        fb, ft = (G if self.lower is not None else 0), (G if self.upper is not None else 0)
+        # rows of an even length (the fp32 multi-step sweeps take two nodes per lane): one extra
+        # column beyond a frame, never on a wall side -- the wall must stay the array's end
+        pad_l = pad_r = 0
+        if (self.nx + fl + fr) % 2:
+            if self.right is not None:
+                pad_r = 1
+            elif self.left is not None:
+                pad_l = 1
+        self.x0, self.y0 = pad_l + fl, fb
+        self.W = pad_l + fl + self.nx + fr + pad_r
+        self.f = torch.zeros((9, fb + self.ny + ft, self.W), dtype=dtype, device=self.device)
+        self.buf = torch.zeros_like(self.f)
+        b.init_rest(self.f, self.rho)          # frames and ghost rows included: the fluid is at rest everywhere
+        self.buf.copy_(self.f)
+        self._col = [torch.empty((9, self.ny, G), dtype=dtype, device=self.device) for _ in range(2)]
+        self._row = [torch.empty((9, G, self.W), dtype=dtype, device=self.device) for _ in range(2)]
+        self.overlap = False
+        self._comm = None
+
+    def _swap_open(self, send_hi, send_lo, recv_lo, recv_hi, hi_rank: Optional[int], lo_rank: Optional[int]) -> bool:
+        """_swap along an axis that does not wrap: a side whose rank is None is a wall, nothing goes
+        there and nothing comes from there.  Between two ranks at most one message travels in each
+        direction, so posting order cannot mix them up."""
+        staged = self.cuda and not self.stream_ordered
+        ops, landed = [], []
+        if hi_rank is not None:
+            ops.append(dist.P2POp(dist.isend, send_hi.cpu() if staged else send_hi, self._peer(hi_rank), self.group))
+        if lo_rank is not None:
+            ops.append(dist.P2POp(dist.isend, send_lo.cpu() if staged else send_lo, self._peer(lo_rank), self.group))
+        for rank, into in ((lo_rank, recv_lo), (hi_rank, recv_hi)):
+            if rank is not None:
+                box = torch.empty(into.shape, dtype=into.dtype, device="cpu") if staged else into
+                ops.append(dist.P2POp(dist.irecv, box, self._peer(rank), self.group))
+                landed.append((into, box))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            for into, box in landed:
+                into.copy_(box)
+        return bool(ops)
+
+    def _exchange_cavity(self) -> None:
+        """Refill the frames of f from the neighbours' owned nodes, all nine populations: columns
+        over the owned rows, then rows over the full width (the corners ride along)."""
+        f, nx, ny, G, x0, y0 = self.f, self.nx, self.ny, self.G, self.x0, self.y0
+        rows = slice(y0, y0 + ny)
+        to_right = f[:, rows, x0 + nx - G:x0 + nx].contiguous() if self.right is not None else None
+        to_left = f[:, rows, x0:x0 + G].contiguous() if self.left is not None else None
+        self._swap_open(to_right, to_left, self._col[0], self._col[1], self.right, self.left)
+        if self.left is not None:
+            f[:, rows, x0 - G:x0] = self._col[0]
+        if self.right is not None:
+            f[:, rows, x0 + nx:x0 + nx + G] = self._col[1]
+        to_up = f[:, y0 + ny - G:y0 + ny, :].contiguous() if self.upper is not None else None
+        to_down = f[:, y0:y0 + G, :].contiguous() if self.lower is not None else None
+        self._swap_open(to_up, to_down, self._row[0], self._row[1], self.upper, self.lower)
+        if self.lower is not None:
+            f[:, y0 - G:y0, :] = self._row[0]
+        if self.upper is not None:
+            f[:, y0 + ny:y0 + ny + G, :] = self._row[1]
 
     # ---- neighbours ---------------------------------------------------------------------------
     def _rank_at(self, cx: int, cy: int) -> int:
@@ -291,9 +403,16 @@ class CartSimulation:
     def _block_deep(self, k: int) -> None:
         """k <= G time steps of the block in one launch, then the frame of the new state."""
         G = self.G
-        self.backend.periodic_fused(self.scheme, self.f, self.buf, self.omega, G, G + self.ny, k)
+        if self.periodic:
+            self.backend.periodic_fused(self.scheme, self.f, self.buf, self.omega, G, G + self.ny, k)
+        else:
+            self.backend.lid_fused(self.scheme, self.f, self.buf, self.omega, self.rho, self.u, self.y0,
+                                   self.y0 + self.ny, self.y_below - self.y0, self.ny_glob, k)
         self.f, self.buf = self.buf, self.f
-        self._exchange_deep()
+        if self.periodic:
+            self._exchange_deep()
+        else:
+            self._exchange_cavity()
         self.t += k
 
     def _return_outflow(self) -> None:
@@ -373,11 +492,10 @@ class CartSimulation:
     def velocities(self) -> torch.Tensor:
         """ux, uy of the owned nodes: [2, ny, nx]."""
         self._complete()
-        G = self.G
         if self._vel is None:
             self._vel = torch.empty((2, self.ny, self.f.shape[2]), dtype=self.f.dtype, device=self.device)
-        self.backend.compute_velocities(self._vel, self.f, G, self.ny + G)
-        return self._vel[:, :, G:self.nx + G]
+        self.backend.compute_velocities(self._vel, self.f, self.y0, self.ny + self.y0)
+        return self._vel[:, :, self.x0:self.nx + self.x0]
 
     def max_velocity(self) -> float:
         """Global max |u| (io.cpp:184-216: float square root, NaN never wins, MPI_Reduce(MAX))."""
@@ -394,8 +512,7 @@ class CartSimulation:
     def interior(self) -> torch.Tensor:
         """The owned nodes without the halo: [9, ny, nx] (a view)."""
         self._complete()
-        G = self.G
-        return self.f[:, G:self.ny + G, G:self.nx + G]
+        return self.f[:, self.y0:self.ny + self.y0, self.x0:self.nx + self.x0]
 
     def gather_populations(self) -> Optional[torch.Tensor]:
         """Rank 0 gets the global [9, NY, NX] populations (for tests / small outputs)."""

@@ -144,6 +144,78 @@ def test_deep_frames_reproduce_the_single_domain_run(world, dims):
         assert vmax == float(orc.max_velocity(want))
 
 
+# the lid-driven cavity cut in both directions: (dtype, nx, ny, steps, omega, frame depth)
+CAVITY_CASES = [
+    ("float32", 24, 18, 25, 1.1, 3),
+    ("float64", 17, 19, 30, 1.7, 4),     # odd rows: the extra column goes beyond a frame, never to a wall
+    ("float64", 13, 11, 20, 0.9, 1),     # frames of one node, one step per exchange
+    ("float32", 20, 21, 16, 0.6, None),  # depth chosen by the backend's plan (5)
+]
+
+
+def _worker_cavity(rank, world, dims, store_path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from lbm_amd.cart import CartSimulation
+    from slab_backend import OracleCartBackend
+    dist.init_process_group("gloo", init_method=f"file://{store_path}", rank=rank, world_size=world)
+    results = {}
+    try:
+        for (tdt, nx, ny, steps, omega, depth) in CAVITY_CASES:
+            for scheme in ("pull", "push"):
+                backend = OracleCartBackend()
+                backend.fused_depth = 5
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cpu", backend=backend,
+                                     dims=dims, scheme=scheme, halo=depth, scene="lid")
+                assert sim.G == (depth or 5)
+                if tdt == "float32" and sim.dims[0] > 1:
+                    assert sim.f.shape[2] % 2 == 0
+                sim.step(steps)
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[(tdt, nx, ny, steps, omega, depth, scheme)] = (full.numpy().copy(), vmax)
+        if rank == 0:
+            torch.save(results, out_path)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, None), (4, None), (3, (1, 3)), (6, None), (3, (3, 1))])
+def test_cavity_blocks_reproduce_the_single_domain_run(world, dims):
+    """The lid-driven cavity on a grid of ranks (the reference refuses it under MPI, main.cpp:317-319):
+    frames only towards neighbours, walls at the array ends of the blocks that touch them; bit for
+    bit the single-domain run, pull and push."""
+    from oracle import oracle as orc
+    with tempfile.TemporaryDirectory() as tmp:
+        store, out = os.path.join(tmp, "store"), os.path.join(tmp, "out.pt")
+        mp.spawn(_worker_cavity, args=(world, dims, store, out), nprocs=world, join=True)
+        results = torch.load(out, weights_only=False)
+    assert len(results) == 2 * len(CAVITY_CASES)
+    for (tdt, nx, ny, steps, omega, depth, scheme), (full, vmax) in results.items():
+        dtype = getattr(np, tdt)
+        want, _ = orc.run("lid", scheme, nx, ny, steps, omega, dtype)
+        bits = np.uint32 if dtype == np.float32 else np.uint64
+        assert (full.view(bits) == want.view(bits)).all(), (world, dims, tdt, nx, ny, depth, scheme)
+        assert vmax == float(orc.max_velocity(want))
+
+
+def test_cavity_on_one_rank_has_no_frames():
+    from oracle import oracle as orc
+    from lbm_amd.cart import CartSimulation
+    from slab_backend import OracleCartBackend
+    for scheme in ("pull", "push"):
+        sim = CartSimulation(9, 7, dtype=torch.float64, omega=1.2, device="cpu", backend=OracleCartBackend(),
+                             scheme=scheme, scene="lid", halo=3)
+        assert tuple(sim.f.shape) == (9, 7, 9) and (sim.x0, sim.y0) == (0, 0)
+        sim.step(11)
+        want, _ = orc.run("lid", scheme, 9, 7, 11, 1.2, np.float64)
+        assert (sim.gather_populations().numpy().view(np.uint64) == want.view(np.uint64)).all(), scheme
+
+
 def test_deep_frames_limits():
     from lbm_amd.cart import CartSimulation
     from slab_backend import OracleCartBackend

@@ -68,11 +68,25 @@ def _worker(rank, world, store_path, out_path):
                 full = sim.gather_populations()
                 if rank == 0:
                     results[case + (scheme, halo)] = (full.cpu().numpy(), vmax, sim.dims, sim.G)
+        for case in CAVITY_CASES:
+            tdt, nx, ny, steps, omega = case
+            for scheme, halo in (("pull", None), ("push", None), ("push", 3), ("pull", 1)):
+                sim = CartSimulation(nx, ny, dtype=getattr(torch, tdt), omega=omega, device="cuda:0", scheme=scheme,
+                                     halo=halo, scene="lid")
+                sim.step(steps)
+                vmax = sim.max_velocity()
+                full = sim.gather_populations()
+                if rank == 0:
+                    results[("lid",) + case + (scheme, halo)] = (full.cpu().numpy(), vmax, sim.dims, sim.G)
         if rank == 0:
             torch.save(results, out_path)
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# the lid-driven cavity cut in both directions: (dtype, nx, ny, steps, omega)
+CAVITY_CASES = [("float32", 256, 96, 30, 1.1), ("float64", 67, 45, 40, 1.7), ("float32", 1030, 517, 12, 0.5)]
 
 
 @pytest.mark.parametrize("world", [4, 6])
@@ -81,12 +95,16 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_domain_run(world, ranks_shar
         out = os.path.join(tmp, "out.pt")
         mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), out), nprocs=world, join=True)
         results = torch.load(out, weights_only=False)
-    assert len(results) == 5 * len(CASES)
-    for (tdt, nx, ny, steps, omega, scheme, halo), (full, vmax, dims, depth) in results.items():
+    assert len(results) == 5 * len(CASES) + 4 * len(CAVITY_CASES)
+    for key, (full, vmax, dims, depth) in results.items():
+        scene = "shear"
+        if key[0] == "lid":
+            scene, key = "lid", key[1:]
+        tdt, nx, ny, steps, omega, scheme, halo = key
         assert dims == ((2, 2) if world == 4 else (3, 2))
         assert depth == halo if halo is not None else depth > 1
-        want, _ = orc.run("shear", scheme, nx, ny, steps, omega, getattr(np, tdt))
-        assert_bits_equal(full, want, f"cart {dims} {scheme} {tdt} {nx}x{ny} frame depth {depth}")
+        want, _ = orc.run(scene, scheme, nx, ny, steps, omega, getattr(np, tdt))
+        assert_bits_equal(full, want, f"cart {dims} {scene} {scheme} {tdt} {nx}x{ny} frame depth {depth}")
         assert vmax == float(orc.max_velocity(want))
 
 
@@ -127,3 +145,20 @@ def test_rccl_transport_with_self_as_every_neighbour():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker_rccl_self, args=(1, 29547, tmp), nprocs=1, join=True)
         assert open(os.path.join(tmp, "result.txt")).read() == "ok"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+def test_cavity_on_one_rank_equals_the_oracle(dtype, scheme):
+    """One rank: no neighbours, no frames -- the block is the cavity."""
+    from lbm_amd.cart import CartSimulation
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    for nx, ny, steps, omega, halo in ((64, 48, 40, 0.8, None), (131, 37, 25, 1.4, 1), (1024, 300, 12, 0.5, None)):
+        if dtype == torch.float32 and nx % 2 and halo != 1:
+            continue
+        sim = CartSimulation(nx, ny, dtype=dtype, omega=omega, scheme=scheme, scene="lid", halo=halo)
+        assert tuple(sim.f.shape) == (9, ny, nx)
+        sim.step(steps)
+        want, _ = orc.run("lid", scheme, nx, ny, steps, omega, npdt)
+        assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 cavity {scheme} {nx}x{ny}")
+        assert sim.max_velocity() == float(orc.max_velocity(want))
