@@ -4,6 +4,12 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The oracle's sweeps are OpenMP loops over rows, one fork/join per time step, and most CPU tests
+# step small lattices thousands of times.  On a shared host whose cores are taken away now and then,
+# every join waits for the slowest of the threads; with all cores in the team the same test was
+# seen to take 4 s or 70 s.  Half the cores unless the environment says otherwise (set before the
+# OpenMP runtime loads).
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(4, (os.cpu_count() or 2) // 2))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

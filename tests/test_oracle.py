@@ -34,9 +34,11 @@ DECAY_RTOL_FMA = 1e-5
 @pytest.mark.parametrize("idx", range(5))
 def test_oracle_matches_recorded_decay_series(decays, idx):
     s = decays["series"][idx]
-    nsamp = 3  # t = 0, 500, 1000 (the full 400-sample series is checked on the GPU)
+    nsamp = 3  # t = 0, 500, 1000; all 400 samples: test_oracle_matches_all_400_recorded_samples
     steps = (nsamp - 1) * decays["every"] + 1
-    _, samples = orc.run("shear", "pull", decays["nx"], decays["ny"], steps, s["omega"], np.float32,
+    # 16 columns print what the recording's 1000 print: the wave does not vary along x and every
+    # column goes through the same arithmetic (the full width runs on the GPU)
+    _, samples = orc.run("shear", "pull", 16, decays["ny"], steps, s["omega"], np.float32,
                          rho=decays["rho0"], u=decays["u0"], out_every=decays["every"])
     assert len(samples) == nsamp
     got = np.array([float(orc.fmt(v)) for v in samples])
@@ -48,7 +50,7 @@ def test_oracle_matches_recorded_decay_series(decays, idx):
 def test_contracting_oracle_build_matches_recorded_decay_series(decays, idx):
     s = decays["series"][idx]
     with orc.variant("fma"):
-        _, samples = orc.run("shear", "pull", decays["nx"], decays["ny"], 1001, s["omega"], np.float32,
+        _, samples = orc.run("shear", "pull", 16, decays["ny"], 1001, s["omega"], np.float32,
                              rho=decays["rho0"], u=decays["u0"], out_every=decays["every"])
     got = np.array([float(orc.fmt(v)) for v in samples])
     np.testing.assert_allclose(got, np.array(s["max_us"][:3]), rtol=DECAY_RTOL_FMA)
