@@ -162,3 +162,19 @@ def test_cavity_on_one_rank_equals_the_oracle(dtype, scheme):
         want, _ = orc.run("lid", scheme, nx, ny, steps, omega, npdt)
         assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart 1x1 cavity {scheme} {nx}x{ny}")
         assert sim.max_velocity() == float(orc.max_velocity(want))
+
+
+@pytest.mark.parametrize("scene", ["shear", "lid"])
+def test_blocks_follow_the_process_wide_arithmetic(scene):
+    """The decomposition calls the same entry points as the single-device loop: with the contracted
+    arithmetic switched on, a block on deep frames holds the bits of the contracted oracle."""
+    from lbm_amd import ops
+    from lbm_amd.cart import CartSimulation
+    with orc.arithmetic("contracted"), ops.arithmetic("contracted"):
+        for scheme in ("pull", "push"):
+            sim = CartSimulation(1024, 300, dtype=torch.float32, omega=0.9, scheme=scheme, scene=scene)
+            assert sim.deep and sim.G >= 5      # what the library plans for a lattice of this size
+            sim.step(21)
+            want, _ = orc.run(scene, scheme, 1024, 300, 21, 0.9, np.float32)
+            assert_bits_equal(sim.gather_populations().cpu().numpy(), want, f"cart contracted {scene} {scheme}")
+    assert ops.get_arithmetic() == "unrolled" and orc.get_arithmetic() == "unrolled"
