@@ -45,6 +45,10 @@ say "== [NY][NX][9] arrays and the rolled arithmetic (strict rounding)"
 bench --layout aos
 bench --layout aos --precision fp64
 bench --layout aos --scene lid --scheme push
+say "== [NY][NX][9] arrays, contracted arithmetic"
+bench --layout aos --arithmetic contracted
+bench --layout aos --precision fp64 --arithmetic contracted
+bench --layout aos --scene lid --scheme push --arithmetic contracted
 bench --rolled
 bench --rolled --scheme push
 say "== odd row lengths"
