@@ -1,7 +1,11 @@
 """The 2-D Cartesian decomposition (lbm_amd.cart) on the GPU: the HIP inner / outer sweeps on a
 block with a halo ring, the packing and the second stream, and the multi-step sweeps on blocks
 with deep frames -- first with the rank as its own neighbour in both directions, then four and
-six ranks sharing cuda:0 over gloo (RCCL refuses several ranks on one GPU)."""
+six ranks sharing cuda:0 over gloo (RCCL refuses several ranks on one GPU).
+
+The file name sorts behind the single-process GPU tests on purpose: the tests that start several
+ranks on one device run last (before the allocation-free entry point's), so that a rank that stalls
+there fails its own test under `pytest -x` without hiding the rest of the suite."""
 import faulthandler
 import os
 import sys

@@ -2,7 +2,7 @@
 set -u
 OUT=gpurun_out/r02_step3
 mkdir -p $OUT
-timeout -k 10 600 python -u -m pytest tests/test_cart_gpu.py tests/test_cli.py -m gpu -x -q --timeout 300 --timeout-method thread > $OUT/tests.log 2>&1
+timeout -k 10 600 python -u -m pytest tests/test_two_d_cart_gpu.py tests/test_cli.py -m gpu -x -q --timeout 300 --timeout-method thread > $OUT/tests.log 2>&1
 rc=$?; tail -4 $OUT/tests.log; [ $rc -eq 0 ] || exit $rc
 cd build
 for g in 1 2 4; do
