@@ -13,9 +13,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "liblbm_hip.so")
-SOURCES = [os.path.join(HERE, "csrc", "lbm_capi.hip")]
+# the C ABI, and the instantiations of the multi-step kernel in five sets that compile side by side
+SOURCES = [os.path.join(HERE, "csrc", "lbm_capi.hip")] + \
+          [os.path.join(HERE, "csrc", f"lbm_fused_inst_{i}.hip") for i in range(1, 6)]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", "lbm_device.h"), os.path.join(HERE, "csrc", "lbm_fused.h"),
-                  os.path.join(ROOT, "include", "lbm_hip.h")]
+                  os.path.join(HERE, "csrc", "lbm_fused_instances.h"), os.path.join(ROOT, "include", "lbm_hip.h")]
+OBJ_DIR = os.path.join(HERE, "csrc", "obj")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -28,10 +31,10 @@ HIPCC_FLAGS = [
     # of them back to back (16384^2 fp32, seven steps per launch: 380 -> 397 GLUPS)
     "-mllvm", "-amdgpu-sched-strategy=max-ilp",
     "-fPIC",
-    "-shared",
     "-Wall",
     "-Wextra",
 ]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs"]   # a kernel no file defines fails the link
 
 
 def hipcc() -> str:
@@ -52,7 +55,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile liblbm_hip.so if missing or older than its sources; return its path."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + SOURCES
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objects = [os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"),
+                                         "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) // 2))) as pool:
+        list(pool.map(compile_one, zip(SOURCES, objects)))    # re-raises the first failure
+    cmd = [hipcc()] + LINK_FLAGS + ["-o", LIB] + objects
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -19,8 +19,12 @@
 
 #include "lbm_device.h"
 #include "lbm_fused.h"
+#include "lbm_fused_instances.h"
 
 #pragma clang fp contract(off)
+
+// the multi-step kernels are compiled in lbm_fused_inst_*.hip, side by side with this file
+LBM_FUSED_ALL_SETS(LBM_FUSED_DECLARE)
 
 namespace {
 

@@ -70,11 +70,19 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
     if not all(os.path.exists(t) or shutil.which(os.path.basename(t)) for t in tools):
         pytest.skip("LLVM binary tools of the ROCm installation not found")
     objcopy, bundler, readelf = tools
-    fat, dev = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([objcopy, f"--dump-section=.hip_fatbin={fat}", capi.LIB_PATH, str(tmp_path / "rest.so")])
-    subprocess.check_call([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                           f"--input={fat}", f"--output={dev}"])
-    notes = subprocess.check_output([readelf, "--notes", dev], text=True)
+    # one offload bundle per source file of the library, back to back in the section
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in the library"
+    notes = ""
+    for n, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        part, dev = str(tmp_path / f"bundle{n}.bin"), str(tmp_path / f"gfx950_{n}.co")
+        open(part, "wb").write(blob[lo:hi])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={part}", f"--output={dev}"])
+        notes += subprocess.check_output([readelf, "--notes", dev], text=True)
     kernels = re.findall(r"\.name:\s+(_Z\S+|\w+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s+(\d+)", notes)
     scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
     vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", notes)]
