@@ -86,6 +86,11 @@
 #ifndef LBM_FUSED_MIN_WAVES
 #define LBM_FUSED_MIN_WAVES 2
 #endif
+// Rows of input staged in the wavefront's LDS ahead of their use by LDS-DMA loads (0 = rows are loaded
+// into registers one or two iterations ahead; see fused_stage_rows()).
+#ifndef LBM_FUSED_STAGE_ROWS
+#define LBM_FUSED_STAGE_ROWS 0
+#endif
 // Wavefronts per workgroup (0 = the built-in choice, fused_group_waves()).
 #ifndef LBM_FUSED_GROUP_WAVES
 #define LBM_FUSED_GROUP_WAVES 0
@@ -109,6 +114,9 @@ constexpr int kFusedMaxSteps = 8;    // 16384^2 fp32 pull, GLUPS at 5/6/7/8 step
 // strips instead of 10, and a 1024^2 launch of five steps runs in 29 us instead of 31.
 template <typename T, int V, int K, bool NARROW = false> constexpr int fused_halo_lanes()
 {
+#ifdef LBM_FUSED_TIMING_NO_HALO
+    return 0;   // timing harnesses only: strips without an x halo (wrong results)
+#endif
     constexpr int granule = NARROW ? V * (int)sizeof(T) : kFusedHaloBytes;
     return ((K * (int)sizeof(T) + granule - 1) / granule) * granule / (V * (int)sizeof(T));
 }
@@ -156,8 +164,22 @@ constexpr int fused_bulk_rings()
     return (!PUSH && r > 3) ? 3 : r;
 }
 
-// LDS of one wavefront: the rings that do not live in registers (4.5 KiB each); for a cavity kernel
-// the larger of its two bodies' needs.
+// Rows of input that a wavefront keeps in flight or landed in its own LDS (LDS-DMA: the loads have no
+// register destination, so looking further ahead costs LDS, not registers).  Periodic sweeps over
+// [9][NY][NX] arrays with eight bytes per lane only; the row length must then be a whole number of
+// 16-byte pieces.  Measured at 16384^2 fp32, one to four rows ahead: launches of five and six steps
+// take exactly as long as with the register prefetch (they run at the rate at which memory serves
+// strips marched down by single wavefronts, with or without the arithmetic), seven and eight lose
+// 2-25 % to the LDS the slots take from the rings.  Off in the library; kept for the tuning harness.
+template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
+constexpr int fused_stage_rows()
+{
+    if (AOS || LID || V * (int)sizeof(T) != kFusedLaneBytes) return 0;
+    return LBM_FUSED_STAGE_ROWS;
+}
+
+// LDS of one wavefront: the rings that do not live in registers (4.5 KiB each) and the staged rows
+// of input (4.5 KiB each); for a cavity kernel the larger of its two bodies' needs.
 template <typename T, int V, int K, bool PUSH, bool LID, bool AOS, int ARITH>
 constexpr int fused_lds_bytes_per_wave()
 {
@@ -165,7 +187,7 @@ constexpr int fused_lds_bytes_per_wave()
     constexpr int own = steps - fused_reg_rings<T, V, K, PUSH, LID, AOS, ARITH>();
     constexpr int bulk = fused_cavity_bulk<LID, AOS, K>() ? steps - fused_bulk_rings<T, V, K, PUSH, AOS, ARITH>() : 0;
     constexpr int rings = own > bulk ? own : bulk;
-    return (rings > 0 ? rings : 0) * 9 * kWave * V * (int)sizeof(T);
+    return ((rings > 0 ? rings : 0) + fused_stage_rows<T, V, K, PUSH, LID, AOS, ARITH>()) * 9 * kWave * V * (int)sizeof(T);
 }
 
 // Wavefronts per workgroup: a launch-time choice, 1 .. kFusedMaxGroupWaves (blockDim.x = 64 x that,
@@ -307,6 +329,71 @@ __device__ __forceinline__ void row_store(T *row, uint32_t bytes, uint32_t voff,
     }
 }
 
+
+// LDS-DMA staging of one row of input (nine population rows of 512 bytes, the strip of one
+// wavefront): loads that write the wavefront's LDS directly and have no register destination.
+// An LDS-DMA load moves 16 bytes per lane to LDS address M0 + 16 x lane, so half a wavefront moves
+// one 512-byte population row; the nine loads go out as five from lanes 0-31 and four from lanes
+// 32-63, population row p landing at lds + 512 p.  Row bases are wave-uniform (scalar registers), a
+// lane adds the byte offset of its 16 bytes.  The compiler neither sees these loads nor waits for
+// them: stage_wait<N>() does (vmcnt counts loads and stores of a wavefront in issue order), and the
+// reads of the LDS slot being refilled must have been issued before (they are waited for here).
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+__device__ __forceinline__ void stage_row_dma(uint32_t lds, uint32_t voff, const void *p0, const void *p1,
+                                              const void *p2, const void *p3, const void *p4, const void *p5,
+                                              const void *p6, const void *p7, const void *p8)
+{
+    uint32_t keep_m0;
+    uint64_t keep_exec;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %[km], m0\n\t"
+        "s_mov_b64 %[ke], exec\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_mov_b32 exec_lo, -1\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p0]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p2]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p4]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p6]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p8]\n\t"
+        "s_mov_b32 exec_lo, 0\n\t"
+        "s_mov_b32 exec_hi, -1\n\t"
+        "s_sub_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p7]\n\t"
+        "s_sub_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p5]\n\t"
+        "s_sub_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p3]\n\t"
+        "s_sub_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[p1]\n\t"
+        "s_mov_b64 exec, %[ke]\n\t"
+        "s_mov_b32 m0, %[km]"
+        : [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)
+        : [lds] "s"(lds), [vo] "v"(voff), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [p4] "s"(p4),
+          [p5] "s"(p5), [p6] "s"(p6), [p7] "s"(p7), [p8] "s"(p8)
+        : "memory", "scc");
+}
+// Wait until at most N vector memory operations of this wavefront are outstanding.
+template <int N> __device__ __forceinline__ void stage_wait()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a six-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // What a lane knows about walls (lid scenes only; all false otherwise).
 struct WallFlags {
     bool t, b;        // destination row is the lid row / the bottom row (wave-uniform)
@@ -387,7 +474,15 @@ __device__ __forceinline__ void gather_row(T (&c)[9][V], const T (&A)[3][V], con
 template <typename T, int V, int ARITH = kArithUnrolled>
 __device__ __forceinline__ void relax_row(T (&o)[9][V], const T (&c)[9][V], const T om)
 {
+#ifdef LBM_FUSED_TIMING_NO_RELAX
+    // timing harnesses only: the sweep's memory traffic without its arithmetic (wrong results)
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[q][e] = c[q][e] * om;
+#else
     collide_nodes<T, V, true, ARITH>(o, c, om);
+#endif
 }
 
 // Array-of-structures lattices ([NY][NX][9], the reference's VIEW(view, x, y, q) = view(y, x, q) of
@@ -499,7 +594,9 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
                   "a lane owns kFusedLaneBytes of a row (one fp32 node when rows have an odd length)");
     constexpr int H = fused_halo_lanes<T, V, K, NARROW>();
     constexpr int W = kWave - 2 * H;         // vectors stored per strip
+#ifndef LBM_FUSED_TIMING_NO_HALO
     static_assert(H * V >= K, "x halo too narrow for K steps");
+#endif
     constexpr bool OWN = PUSH || AOS;        // a row is loaded as its own nine populations
     constexpr int NG = fused_ring_steps<K, PUSH, AOS>();   // streaming steps done in registers or LDS
     constexpr int D = NG;                    // rows between a segment's first row and the first row relaxed
@@ -794,6 +891,77 @@ __device__ __forceinline__ void fused_body(const T *__restrict__ f, T *__restric
     // a loop unrolled by PF + 1.  One iteration of fp64 work (~0.8 us) is shorter than the memory
     // latency under load, so fp64 looks two rows ahead (37 % of its wave time sat in s_waitcnt with
     // one); fp32 gains nothing from a second row.
+    constexpr int SR = fused_stage_rows<T, V, K, PUSH, LID, AOS, ARITH>();
+    if constexpr (SR > 0 && !NARROW) {
+        // Rows travel through this wavefront's LDS, SR rows ahead: slot j holds row i0 + j until
+        // iteration i0 + j has read it into registers, and is then refilled with row i0 + j + SR.
+        // Lane l of an LDS-DMA load (l mod 32 in its half of the wavefront) fetches the 16 bytes of
+        // the 8-byte lanes 2l and 2l+1 of the strip; first lane, halo and stored width of a strip are
+        // even and so must be the row length in 8-byte lanes: the pair then never straddles the
+        // periodic wrap.
+        static_assert(!LID, "staged rows are built for the periodic sweeps");
+        constexpr uint32_t kRowB = 9 * kWave * V * (uint32_t)sizeof(T);
+        const uint32_t dl = lane % 32u;
+        int64_t px = ((int64_t)strip * W - H + 2 * (int64_t)dl) % (int64_t)nxv;
+        if (px < 0) px += nxv;
+        const uint32_t doff = (uint32_t)px * (uint32_t)kFusedLaneBytes;
+        const uint32_t stage0 = (uint32_t)(uintptr_t)(lds_byte_t *)fused_lds_raw + work.lds_base +
+                                (uint32_t)NLDS * kRowB;
+        // population held by slot position p: the order of the loads of the unstaged form
+        constexpr int kPullPop[9] = {7, 4, 8, 3, 0, 1, 6, 2, 5};
+        // request the next row into the slot at byte offset `slot` of the staging area
+        auto stage_issue = [&](uint32_t slot) {
+            const uint32_t y = y_m, yd = y_d, yu = y_u;
+            const uint32_t dst = stage0 + slot;
+            if (PUSH) {
+                stage_row_dma(dst, doff, rowp(f, plane, 0, y, g.nx), rowp(f, plane, 1, y, g.nx), rowp(f, plane, 2, y, g.nx),
+                              rowp(f, plane, 3, y, g.nx), rowp(f, plane, 4, y, g.nx), rowp(f, plane, 5, y, g.nx),
+                              rowp(f, plane, 6, y, g.nx), rowp(f, plane, 7, y, g.nx), rowp(f, plane, 8, y, g.nx));
+            } else {
+                stage_row_dma(dst, doff, rowp(f, plane, 7, yu, g.nx), rowp(f, plane, 4, yu, g.nx), rowp(f, plane, 8, yu, g.nx),
+                              rowp(f, plane, 3, y, g.nx), rowp(f, plane, 0, y, g.nx), rowp(f, plane, 1, y, g.nx),
+                              rowp(f, plane, 6, yd, g.nx), rowp(f, plane, 2, yd, g.nx), rowp(f, plane, 5, yd, g.nx));
+            }
+            advance_rows();
+        };
+        auto stage_read = [&](RowIn<T, V> &cur, uint32_t slot) {
+            const ring_vec_t(*src)[kWave] = reinterpret_cast<const ring_vec_t(*)[kWave]>(
+                fused_lds_raw + work.lds_base + (uint32_t)NLDS * kRowB + slot);
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                const ring_vec_t v = src[p][lane];
+#pragma unroll
+                for (int e = 0; e < V; ++e) cur.v[PUSH ? p : kPullPop[p]][e] = v[e];
+            }
+        };
+        const T nothing[V] = {};
+#pragma unroll
+        for (int j = 0; j < SR; ++j) {
+            stage_issue((uint32_t)j * kRowB);
+            // as many (dropped) stores behind every request as an iteration issues: the count that
+            // stage_wait takes is then the same from the first iteration on
+#pragma unroll
+            for (int q = 0; q < 9; ++q) row_store<T, V>(rowp(buf, plane, q, ys, g.nx), 0u, kNoStore, nothing);
+        }
+        // operations issued behind the request for a row when its turn comes: the stores of the
+        // iteration that requested it, then SR - 1 iterations of nine loads and nine stores
+        constexpr int kBehind = 9 + (SR - 1) * 18;
+        {
+            uint32_t slot = 0;
+            for (uint32_t i = 0; i < iters; ++i) {
+                stage_wait<kBehind>();
+                RowIn<T, V> cur;
+                stage_read(cur, slot);
+                cur.w[0] = T(0);
+                cur.w[1] = T(0);
+                stage_issue(slot);
+                iteration(cur, i);
+                slot = slot + kRowB == SR * kRowB ? 0u : slot + kRowB;
+            }
+        }
+        stage_wait<0>();   // nothing may still be on its way into LDS that the next workgroup owns
+        return;
+    }
     constexpr int PF = (sizeof(T) == 8 && V == 1) ? LBM_FUSED_PREFETCH_F64 : LBM_FUSED_PREFETCH_F32;
     RowIn<T, V> in[PF + 1];
 #pragma unroll

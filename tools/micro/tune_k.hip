@@ -103,6 +103,9 @@ int main(int argc, char **argv)
     for (int K : ks) {
         for (uint32_t S : segs.empty() ? std::vector<uint32_t>{pick_seg(nx, ny, K, 2048)} : segs)
         switch (K) {
+            case 1: add<1>(vs, nx, ny, om, S); break;
+            case 2: add<2>(vs, nx, ny, om, S); break;
+            case 3: add<3>(vs, nx, ny, om, S); break;
             case 4: add<4>(vs, nx, ny, om, S); break;
             case 5: add<5>(vs, nx, ny, om, S); break;
             case 6: add<6>(vs, nx, ny, om, S); break;
