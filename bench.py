@@ -7,29 +7,28 @@
 One "step" is one time step: every node of the lattice relaxed and streamed once.  The time loop
 hands runs of up to eight steps to one fused launch (same populations bit for bit, one
 pass over HBM instead of six); --max-fuse 1 times the one-step sweep instead.  N=1 runs the single-GPU
-configuration (shear-wave decay, 16384 x 16384, fp32, pull streaming).  N>1 (launched by
-torch.distributed.run, one rank per GPU) gives every rank a 16384 x 16384 y-slab of a
-16384 x (16384*N) lattice and refreshes up to eight ghost rows per slab edge once per as many steps over
-RCCL, overlapped with the interior update: weak scaling, value = all ranks' lattice updates per
-second.
+configuration (shear-wave decay, 16384 x 16384, fp32, pull streaming: BASELINE configs[2]).  N>1
+(launched by torch.distributed.run, one rank per GPU) runs BASELINE configs[4]: every rank owns a
+32768 x 4096 y-slab of a 32768 x (4096*N) lattice (weak scaling; --strong: a 32768 x 32768 lattice
+split over the ranks) and refreshes up to eight ghost rows per slab edge once per as many steps over
+RCCL, overlapped with the interior update; value = all ranks' lattice updates per second.
 
 Inputs are resident in HBM when the clock starts (allocation and initialisation are outside the
 timed region); the timed region is bracketed by barrier + device synchronise on both sides and the
 maximum over ranks is reported.
 
 The JSON line also carries
-  roofline:     algorithmic HBM bytes of one sweep launch (72 B per node and time step fp32, 144 B
-                fp64: 9 reads + 9 writes, times the steps the launch advances) / the launch duration
-                measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak.  A
-                fused launch moves fewer bytes than that count (its own compulsory traffic is 72 B
-                per node whatever the step count: `min_bytes_per_launch`), so `frac` can exceed 1;
-                `hbm_frac` prices the bytes actually moved (PMC `traffic` when a profile of this
-                workload is committed, else `min_bytes_per_launch`);
-                A second roof stands next to it for a fused launch, which is not bound by the
-                algorithmic bytes: `valu` = vector-ALU wave-instructions of the launch (PMC
-                SQ_INSTS_VALU of a committed profile) x 4 cycles / (1024 SIMDs x 2.4 GHz); `binding`
-                names the larger of the two floors and `frac_of_binding_roof` = that floor / the
-                measured launch time.  Both floors are priced at the peaks; the same profile also
+  roofline:     the roof that binds the dominant sweep launch, whose duration is measured with HIP
+                events on the launch stream.  Two floors are priced at the nominal peaks: `hbm` = the
+                bytes the launch moves through HBM (PMC `traffic` = FETCH_SIZE x 2 + WRITE_SIZE when a
+                profile of this workload is committed, else its compulsory bytes
+                `min_bytes_per_launch`) / 8 TB/s, and `valu` = its vector-ALU wave-instructions (PMC
+                SQ_INSTS_VALU of the same profile) x 4 cycles / (1024 SIMDs x 2.4 GHz).  `bound` names
+                the larger floor, `achieved` / `peak` are that resource's rate and peak, `frac` =
+                achieved / peak = floor / measured time (<= 1).  The algorithmic figure of a one-step
+                sweep (72 B per node and time step fp32, 144 B fp64, times the steps the launch
+                advances) is kept as `algorithmic_achieved` / `algorithmic_over_peak`: a fused launch
+                moves fewer bytes than that count, so it exceeds 1 and bounds nothing.  The same profile also
                 records what the part delivers (copy ceiling 6.2 TB/s, engine clock under this load
                 ~1.8-2.0 GHz): `hbm_frac_of_copy_ceiling`, `valu.frac_at_profiled_clock`, and the larger
                 of those two floors as `binding_as_delivered` / `frac_of_binding_roof_as_delivered`;
@@ -65,19 +64,26 @@ def parse():
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--scheme", choices=["pull", "push"], default="pull")
     ap.add_argument("--scene", choices=["shear", "lid"], default="shear")
-    ap.add_argument("--nx", type=int, default=16384)
-    ap.add_argument("--ny-per-gpu", type=int, default=16384)
+    ap.add_argument("--nx", type=int, default=None,
+                    help="row length (default: 16384 on one GPU, 32768 on several = BASELINE configs[2] / configs[4])")
+    ap.add_argument("--ny-per-gpu", type=int, default=None,
+                    help="rows per rank (default: 16384 on one GPU; 4096 on several: the weak-scaling slab of "
+                         "BASELINE configs[4], 32768 x 4096 per GPU)")
     ap.add_argument("--ny-global", type=int, default=0,
                     help="strong scaling: fixed global height split over the ranks (overrides --ny-per-gpu), "
                          "e.g. --nx 32768 --ny-global 32768")
+    ap.add_argument("--strong", action="store_true",
+                    help="several GPUs: the strong-scaling shape of BASELINE configs[4], a 32768 x 32768 lattice split "
+                         "over the ranks (= --nx 32768 --ny-global 32768)")
     ap.add_argument("--omega", type=float, default=0.5)
     ap.add_argument("--rolled", action="store_true",
                     help="the reference's UNROLL_LOOPS=false arithmetic in the periodic sweeps (shear scene)")
-    ap.add_argument("--arithmetic", choices=["unrolled", "contracted"], default=None,
-                    help="contracted (default) = the relaxation with the multiply-adds fused that the reference's own "
-                         "build flags let a compiler fuse (LBM_ARITH_CONTRACTED), checked bit for bit against the "
-                         "oracle's restatement of the same contraction and within 1e-5 / 1e-12 of the strict one; "
-                         "unrolled = every operation rounded where the reference's text puts it (the library default)")
+    ap.add_argument("--arithmetic", choices=["unrolled", "strict", "contracted"], default=None,
+                    help="contracted (the default of the library, of ./main and of this script) = the relaxation with the "
+                         "multiply-adds fused that the reference's own build flags let a compiler fuse "
+                         "(LBM_ARITH_CONTRACTED), checked bit for bit against the oracle's restatement of the same "
+                         "contraction and within 1e-5 / 1e-12 of the strict one; strict = unrolled = every operation "
+                         "rounded where the reference's text puts it (LBM_ARITHMETIC=strict)")
     ap.add_argument("--layout", choices=["soa", "aos"], default="soa",
                     help="aos = [NY][NX][9] arrays, the reference's COALESCING=false (single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,21 +221,32 @@ def main():
 
     dtype = torch.float32 if args.precision == "fp32" else torch.float64
     bytes_per_node = 72 if args.precision == "fp32" else 144
-    nx, ny_loc = args.nx, args.ny_per_gpu
+    # Shapes nobody asked for otherwise are BASELINE.json's: configs[2] on one GPU (16384 x 16384), configs[4]
+    # on several (weak: a 32768 x 4096 slab per GPU; --strong: 32768 x 32768 split over the ranks)
+    baseline_shape = args.nx is None and args.ny_per_gpu is None and args.ny_global == 0
+    if args.strong:
+        if args.ny_global or args.ny_per_gpu:
+            raise SystemExit("--strong fixes the global height; do not combine it with --ny-global / --ny-per-gpu")
+        args.ny_global = 32768
+        args.nx = args.nx or 32768
+    nx = args.nx or (16384 if world == 1 else 32768)
+    ny_loc = args.ny_per_gpu or (16384 if world == 1 else 4096)
     ny_glob = ny_loc * world
     strong = args.ny_global > 0
     if strong:
         ny_glob = args.ny_global
         ny_loc = -(-ny_glob // world)   # the largest slab (remainder rows go to the lowest ranks)
 
+    if args.arithmetic == "strict":
+        args.arithmetic = "unrolled"
     if args.arithmetic is None:
         args.arithmetic = "unrolled" if (args.rolled or args.layout == "aos") else "contracted"
     if args.rolled:
         ops.set_unroll_loops(False)
-    if args.arithmetic == "contracted":
-        if args.rolled:
-            raise SystemExit("--arithmetic contracted does not go with --rolled")
-        ops.set_arithmetic("contracted")
+    if args.arithmetic == "contracted" and args.rolled:
+        raise SystemExit("--arithmetic contracted does not go with --rolled")
+    if not args.rolled:
+        ops.set_arithmetic(args.arithmetic)   # whatever LBM_ARITHMETIC says: the line names what ran
     if args.layout == "aos":
         if world != 1 or args.slab:
             raise SystemExit("--layout aos runs on one GPU without the slab path")
@@ -364,6 +381,14 @@ def main():
         achieved = alg_bytes / launch_s / 1e9
         workload = (f"{'shear-wave decay' if args.scene == 'shear' else 'lid-driven cavity'} "
                     f"{nx}x{ny_glob} {args.precision} {args.scheme}")
+        if world > 1:
+            workload += f", {world} y-slabs of {nx}x{ny_loc}"
+        if baseline_shape or args.strong:
+            if world == 1:
+                workload += " (BASELINE configs[2])" if (args.scene, args.scheme, args.precision) == ("shear", "pull", "fp32") else ""
+            else:
+                workload += (" (BASELINE configs[4], strong scaling: 32768x32768 over the GPUs)" if strong else
+                             " (BASELINE configs[4], weak scaling: a 32768x4096 slab per GPU)")
         key = f"{args.scene}-{args.scheme}-{args.precision}-{nx}x{ny_loc}" + ("-aos" if args.layout == "aos" else "") + ("-rolled" if args.rolled else "") + ("-contracted" if args.arithmetic == "contracted" else "")
         # profiles are keyed by the step count of the dominant launches
         if k_dom != 1:
@@ -387,10 +412,21 @@ def main():
         if valu_floor_seen_s:
             delivered["valu"] = valu_floor_seen_s
         binding_delivered = max(delivered, key=delivered.get)
+        # the roof that binds the dominant launch, at the nominal peaks: HBM bytes moved (counters of a committed
+        # profile, else the compulsory bytes) against 8 TB/s, or vector-ALU wave-instructions against
+        # 1024 SIMDs x 2.4 GHz / 4 cycles -- whichever floor is the larger
+        hbm_bytes = traffic if traffic else min_bytes
+        valu_peak_ginst = N_SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
+        if binding == "valu":
+            roof_achieved, roof_peak, roof_unit = valu_insts / launch_s / 1e9, valu_peak_ginst, "Gwave-inst/s"
+        else:
+            roof_achieved, roof_peak, roof_unit = hbm_bytes / launch_s / 1e9, HBM_PEAK_GBS, "GB/s"
         out = {
             "metric": "MLUPS",
             "value": mlups,
             "unit": "MLUPS",
+            "arithmetic": "rolled loops (UNROLL_LOOPS=false)" if args.rolled else
+                          {"contracted": "contracted (library default)", "unrolled": "strict (LBM_ARITHMETIC=strict)"}[args.arithmetic],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -418,12 +454,14 @@ def main():
                 "max_velocity_after_run": vmax,
             },
             "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "bound": binding,
+                "achieved": roof_achieved,
+                "peak": roof_peak,
+                "unit": roof_unit,
+                "frac": roof_achieved / roof_peak,
                 "traffic": traffic,
+                "algorithmic_achieved": achieved,
+                "algorithmic_over_peak": achieved / HBM_PEAK_GBS,
                 "kernel": (f"{args.scheme} {'periodic' if args.scene == 'shear' else 'lid-driven'} sweep, "
                            f"{k_dom} time step(s) per launch"),
                 "steps_per_launch": k_dom,
@@ -448,10 +486,11 @@ def main():
                 "frac_of_binding_roof_as_delivered": delivered[binding_delivered] / launch_s,
                 "profile": prof.get("source"),
                 "launch_ms": launch_s * 1e3,
-                "note": ("one launch advances several time steps per pass over HBM, so the algorithmic rate "
-                         "(72/144 B per node and step) can exceed the HBM peak; hbm_frac prices the bytes "
-                         "actually moved (traffic if profiled, else min_bytes_per_launch)") if k_dom != 1 else
-                        "one time step per launch",
+                "note": ("frac = the larger of the launch's two floors at the nominal peaks (HBM bytes actually moved / "
+                         "8 TB/s; vector-ALU wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz) over its measured "
+                         "duration; one launch advances several time steps per pass over HBM, so the algorithmic rate "
+                         "(72/144 B per node and step: algorithmic_achieved) can exceed the HBM peak and bounds nothing")
+                        if k_dom != 1 else "one time step per launch",
             },
         }
         out["parity_checked"] = all(r["parity_checked"] for r in reports)

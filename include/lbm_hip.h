@@ -69,29 +69,34 @@ int lbm_get_layout(void);
  * between two spellings of the BGK relaxation in the periodic sweeps: pull_periodic / push_periodic
  * (pull-push.cpp:5-73, :124-186; unrolled != 0, the default) and pull_periodic_for /
  * push_periodic_for (pull-push.cpp:77-120, :190-243; unrolled == 0), which round the equilibrium
- * differently (4.5*(c*c) instead of (4.5*c)*c) and so differ in the last bits.  Each is followed
- * literally.  The lid-driven sweeps have one spelling in the reference and ignore the switch.  With
- * unrolled == 0 the *_fused entry points need fp32 rows of an even length >= 4, and [NY][NX][9]
- * arrays are not supported. */
+ * differently (4.5*(c*c) instead of (4.5*c)*c) and so differ in the last bits.  The lid-driven sweeps
+ * have one spelling in the reference and ignore the switch.  unrolled == 0 selects LBM_ARITH_ROLLED;
+ * unrolled != 0 leaves any other arithmetic as it is and turns LBM_ARITH_ROLLED back into the
+ * arithmetic the process started with.  With unrolled == 0 the *_fused entry points need fp32 rows
+ * of an even length >= 4, and [NY][NX][9] arrays are not supported. */
 int lbm_set_unroll_loops(int unrolled);
 int lbm_get_unroll_loops(void);
 
 /* Spelling of the BGK relaxation, process-wide (a superset of lbm_set_unroll_loops):
- *   LBM_ARITH_UNROLLED    pull_periodic / push_periodic / push_lid_driven as written
- *                         (pull-push.cpp:25-72, :138-185, :454-483), every operation rounded where the
- *                         source text puts it; the default.
- *   LBM_ARITH_ROLLED      the *_for functions (pull-push.cpp:77-120, :190-243) = lbm_set_unroll_loops(0).
- *   LBM_ARITH_CONTRACTED  the unrolled spelling with the multiply-adds fused that a compiler may fuse
- *                         under the reference's own build flags (-O3 -march=native, CMakeLists.txt:18;
- *                         nvcc and hipcc contract by default): ux*ux+uy*uy, 1 -+ 3a, + (4.5a)a,
- *                         w*(...) - f and f + om*(...) each become one fused multiply-add; sums, the
- *                         reciprocal of the density (correctly rounded) and all other products are
- *                         unchanged.  A third fewer vector instructions per node.  Populations stay within the parity budget of
- *                         the unrolled spelling (fp32 1e-5, fp64 1e-12 max-abs over thousands of
- *                         steps; measured 3e-7 / 1e-15).  All sweeps in both layouts; fp32 rows must
+ *   LBM_ARITH_CONTRACTED  the default.  pull_periodic / push_periodic / push_lid_driven
+ *                         (pull-push.cpp:25-72, :138-185, :454-483) with the multiply-adds fused that
+ *                         a compiler may fuse under the reference's own build flags (-O3
+ *                         -march=native, CMakeLists.txt:18; nvcc and hipcc contract by default):
+ *                         ux*ux+uy*uy, 1 -+ 3a, + (4.5a)a, w*(...) - f and f + om*(...) each become
+ *                         one fused multiply-add; sums, the reciprocal of the density (correctly
+ *                         rounded) and all other products are unchanged.  The contraction is spelled
+ *                         out with explicit fma calls, so it does not depend on compiler flags and a
+ *                         CPU restatement can follow it bit for bit.  A third fewer vector
+ *                         instructions per node than the strict spelling.  Populations stay within
+ *                         1e-5 (fp32) / 1e-12 (fp64) max-abs of the strict spelling over thousands of
+ *                         steps (measured 3e-7 / 1e-15).  All sweeps in both layouts; fp32 rows must
  *                         have an even length >= 4 for the *_fused entry points (on [NY][NX][9]
  *                         arrays for every sweep).
- * The environment variable LBM_ARITHMETIC (unrolled | rolled | contracted) sets the initial value. */
+ *   LBM_ARITH_UNROLLED    the same functions with every operation rounded where the source text puts
+ *                         it ("strict"): what a build of the reference with -ffp-contract=off computes.
+ *   LBM_ARITH_ROLLED      the *_for functions (pull-push.cpp:77-120, :190-243) = lbm_set_unroll_loops(0).
+ * The environment variable LBM_ARITHMETIC (contracted | strict = unrolled | rolled) names the value a
+ * process starts with. */
 enum { LBM_ARITH_UNROLLED = 0, LBM_ARITH_ROLLED = 1, LBM_ARITH_CONTRACTED = 2 };
 int lbm_set_arithmetic(int arithmetic);
 int lbm_get_arithmetic(void);
@@ -101,6 +106,46 @@ int lbm_get_arithmetic(void);
  * cap on resident waves per compute unit for the sweep kernels (1..32; the sweeps stream fastest
  * with about 8-12).  0 keeps the built-in choice for that parameter.  Process-wide. */
 int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu);
+
+/* Settings that travel with a caller instead of with the process.  The reference fixes layout and
+ * arithmetic per build (macros.h:5-8) and its launch tile per run (global.h:95-98); the process-wide
+ * setters above mirror that.  A context carries its own copy of the four settings -- layout,
+ * arithmetic, threads_x, waves_per_cu -- so that two simulations with different settings can live in
+ * one process and a setter called on one thread cannot change what another thread computes.
+ *   lbm_ctx_create        new context; its settings start as those in force for the calling thread
+ *                         (its current context's, else the process-wide ones).
+ *   lbm_ctx_set_* / get_* change / read the context's own settings (same values and errors as the
+ *                         process-wide setters).
+ *   lbm_ctx_make_current  makes `ctx` the current context of the CALLING HOST THREAD: every entry
+ *                         point of this header called from that thread then runs under the
+ *                         context's settings; NULL returns the thread to the process-wide settings.
+ *                         A thread that never calls it behaves as before.
+ *   lbm_ctx_get_current   the calling thread's current context, or NULL.
+ *   lbm_ctx_destroy       frees the context (and un-currents it on the calling thread if it is
+ *                         current there; other threads must have dropped it before).
+ * A context is plain host state: it owns no device memory and no stream, and it may be current on
+ * several threads as long as nobody changes its settings meanwhile. */
+typedef struct lbm_ctx lbm_ctx;
+int lbm_ctx_create(lbm_ctx **out);
+int lbm_ctx_destroy(lbm_ctx *ctx);
+int lbm_ctx_make_current(lbm_ctx *ctx);
+lbm_ctx *lbm_ctx_get_current(void);
+int lbm_ctx_set_layout(lbm_ctx *ctx, int layout);
+int lbm_ctx_set_arithmetic(lbm_ctx *ctx, int arithmetic);
+int lbm_ctx_set_launch_shape(lbm_ctx *ctx, unsigned threads_x, unsigned waves_per_cu);
+int lbm_ctx_get_layout(const lbm_ctx *ctx);      /* -1 for a null context */
+int lbm_ctx_get_arithmetic(const lbm_ctx *ctx);  /* -1 for a null context */
+
+/* Tuning and test switches of the multi-step launches (process-wide; no counterpart in the
+ * reference).  The environment variables LBM_FUSED_NARROW, LBM_FUSED_GROUP, LBM_FUSED_BULK,
+ * LBM_FUSED_MAX_STEPS and LBM_FUSED_MIN_NODES name their start values, read once when the library is loaded; this call
+ * changes one afterwards.  name: "fused_narrow" (0 never / 1 where it saves a strip / 2 always:
+ * halos of whole lanes on small periodic lattices), "fused_group" (-1 built-in / 0 single
+ * wavefronts / 1 groups of wavefronts wherever the kernel allows), "fused_bulk" (0: every
+ * wavefront of a cavity launch runs the code with the wall cases), "fused_max_steps" (0 built-in,
+ * else the most steps lbm_plan_steps hands to one launch), "fused_min_nodes" (0 none, else
+ * lattices with fewer nodes take one step per launch). */
+int lbm_set_tuning(const char *name, int value);
 
 /* ---------------------------------------------------------------- initialisation ----------- */
 

@@ -28,6 +28,16 @@ SIGNATURES = {
     "lbm_set_arithmetic": (_int, [_int]),
     "lbm_get_arithmetic": (_int, []),
     "lbm_set_launch_shape": (_int, [_uint, _uint]),
+    "lbm_ctx_create": (_int, [C.POINTER(_ptr)]),
+    "lbm_ctx_destroy": (_int, [_ptr]),
+    "lbm_ctx_make_current": (_int, [_ptr]),
+    "lbm_ctx_get_current": (_ptr, []),
+    "lbm_ctx_set_layout": (_int, [_ptr, _int]),
+    "lbm_ctx_set_arithmetic": (_int, [_ptr, _int]),
+    "lbm_ctx_set_launch_shape": (_int, [_ptr, _uint, _uint]),
+    "lbm_ctx_get_layout": (_int, [_ptr]),
+    "lbm_ctx_get_arithmetic": (_int, [_ptr]),
+    "lbm_set_tuning": (_int, [C.c_char_p, _int]),
     "lbm_init_shearwave": (_int, [_ptr, _int, _u64, _u64, _dbl, _dbl, _u64, _u64, _uint, _ptr]),
     "lbm_init_rest": (_int, [_ptr, _int, _u64, _u64, _dbl, _ptr]),
     "lbm_pull_periodic_no_mpi": (_int, [_ptr, _ptr, _int, _u64, _u64, _dbl, _ptr]),

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "lbm_device.h"
@@ -25,6 +26,13 @@
 
 // the multi-step kernels are compiled in lbm_fused_inst_*.hip, side by side with this file
 LBM_FUSED_ALL_SETS(LBM_FUSED_DECLARE)
+
+// Settings that travel with a caller instead of with the process (include/lbm_hip.h, lbm_ctx_*).
+struct lbm_ctx {
+    int layout;
+    int arith;
+    unsigned threads_x, waves_per_cu;
+};
 
 namespace {
 
@@ -50,20 +58,32 @@ int fail(int status, const char *fmt, ...)
 // memory layout of every distribution array passed in (lbm_set_layout)
 std::atomic<int> g_layout{LBM_LAYOUT_SOA};
 
-// spelling of the relaxation (lbm_set_arithmetic / lbm_set_unroll_loops): lbm::kArithUnrolled (default),
-// kArithRolled (the reference's UNROLL_LOOPS=false spelling; periodic sweeps only) or kArithContracted
+// spelling of the relaxation (lbm_set_arithmetic / lbm_set_unroll_loops): lbm::kArithContracted (the
+// default: the reference is built with contraction allowed, CMakeLists.txt:18), kArithUnrolled
+// (LBM_ARITHMETIC=strict: every operation rounded where pull-push.cpp:25-72 puts it) or kArithRolled
+// (the reference's UNROLL_LOOPS=false spelling; periodic sweeps only).  The environment variable
+// names the default a process starts with.
 int arithmetic_default()
 {
     const char *e = getenv("LBM_ARITHMETIC");
-    if (e && strcmp(e, "contracted") == 0) return lbm::kArithContracted;
+    if (e && (strcmp(e, "strict") == 0 || strcmp(e, "unrolled") == 0)) return lbm::kArithUnrolled;
     if (e && strcmp(e, "rolled") == 0) return lbm::kArithRolled;
-    return lbm::kArithUnrolled;
+    return lbm::kArithContracted;
 }
 std::atomic<int> g_arith{arithmetic_default()};
 
 // launch-shape hint (lbm_set_launch_shape)
 std::atomic<unsigned> g_threads_x{0};
 std::atomic<unsigned> g_waves_per_cu{0};
+
+// The settings a call runs under: those of the context that is current on the calling host thread
+// (lbm_ctx_make_current), else the process-wide ones above.  Every entry point reads them through
+// these accessors, once per decision.
+thread_local lbm_ctx *t_ctx = nullptr;
+int cur_layout() { return t_ctx ? t_ctx->layout : g_layout.load(); }
+int cur_arith() { return t_ctx ? t_ctx->arith : g_arith.load(); }
+unsigned cur_threads_x() { return t_ctx ? t_ctx->threads_x : g_threads_x.load(); }
+unsigned cur_waves_per_cu() { return t_ctx ? t_ctx->waves_per_cu : g_waves_per_cu.load(); }
 
 // Measured on MI355X (16384^2, straight-line sweeps, nt stores, 64-lane workgroups): the achieved
 // HBM rate is flat at 4-6 resident waves per CU (fp32 pull 6.06-6.13 TB/s), falls off a cliff at 7
@@ -139,7 +159,7 @@ int check_rows(uint64_t ny, uint64_t y_lo, uint64_t y_hi, bool needs_ghosts)
 
 unsigned pick_block(uint64_t lanes_per_row)
 {
-    const unsigned tx = g_threads_x.load();
+    const unsigned tx = cur_threads_x();
     unsigned b = tx ? tx : kDefaultThreadsX;
     // do not launch workgroups much wider than a row
     while (b > 64 && (uint64_t)b / 2 >= lanes_per_row) b /= 2;
@@ -161,7 +181,7 @@ size_t residency_ballast(unsigned block, size_t elem_size, bool pull, uint64_t n
     // both arrays resident in the 256 MiB Infinity Cache: the L2 cliff does not bite and more waves
     // hide more latency (1024^2 fp32: 66.3 GLUPS at 16-24 waves/CU against 64.5 at 6)
     const bool cache_resident = 2ull * 9ull * nx * ny * elem_size <= (192ull << 20);
-    const unsigned wpc = g_waves_per_cu.load();
+    const unsigned wpc = cur_waves_per_cu();
     const unsigned waves = wpc ? wpc
                            : cache_resident ? kWavesPerCU_cache_resident
                            : (elem_size == 4 ? kWavesPerCU_f32 : (pull ? kWavesPerCU_f64_pull : kWavesPerCU_f64_push));
@@ -269,7 +289,7 @@ template <typename T, bool PULL>
 int sweep_periodic_rows(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, uint64_t y_lo, uint64_t y_hi,
                         int wrap_y, hipStream_t stream)
 {
-    switch (g_arith.load()) {
+    switch (cur_arith()) {
         case lbm::kArithRolled: return sweep_periodic_rows_as<T, PULL, lbm::kArithRolled>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
         case lbm::kArithContracted: return sweep_periodic_rows_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
         default: return sweep_periodic_rows_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, stream);
@@ -282,7 +302,7 @@ int periodic_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, 
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
     if (int s = check_rows(ny, y_lo, y_hi, !wrap_y)) return s;
-    if (g_layout == LBM_LAYOUT_AOS) return aos_one_step<PULL, false>(f, buf, prec, nx, ny, om, 0., 0., y_lo, y_hi, wrap_y, 0, 0, stream);
+    if (cur_layout() == LBM_LAYOUT_AOS) return aos_one_step<PULL, false>(f, buf, prec, nx, ny, om, 0., 0., y_lo, y_hi, wrap_y, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
                ? sweep_periodic_rows<float, PULL>(f, buf, nx, ny, om, y_lo, y_hi, wrap_y, st)
@@ -320,7 +340,7 @@ template <typename T, bool PULL>
 int sweep_inner(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, uint64_t LX, uint64_t LY, uint64_t HX,
                 uint64_t HY, hipStream_t stream)
 {
-    switch (g_arith.load()) {
+    switch (cur_arith()) {
         case lbm::kArithRolled: return sweep_inner_as<T, PULL, lbm::kArithRolled>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
         case lbm::kArithContracted: return sweep_inner_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
         default: return sweep_inner_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, LX, LY, HX, HY, stream);
@@ -332,7 +352,7 @@ int inner(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double o
           uint64_t LY, uint64_t HX, uint64_t HY, void *stream)
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
-    if (g_layout == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
+    if (cur_layout() == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
     if (HX > nx || HY > ny || LX > HX || LY > HY)
         return fail(LBM_ERR_INVALID_ARGUMENT, "rectangle [%llu,%llu)x[%llu,%llu) outside %llux%llu",
                     (unsigned long long)LX, (unsigned long long)HX, (unsigned long long)LY,
@@ -349,10 +369,10 @@ int sweep_outer(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
 {
     const uint64_t lanes = (nx - 2) + (ny - 4);
     constexpr int B = 256;
-    if (g_arith == lbm::kArithRolled)
+    if (cur_arith() == lbm::kArithRolled)
         hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, lbm::kArithRolled>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
                            stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
-    else if (g_arith == lbm::kArithContracted)
+    else if (cur_arith() == lbm::kArithContracted)
         hipLaunchKernelGGL((lbm::k_outer_ring<T, PULL, B, lbm::kArithContracted>), dim3((unsigned)((lanes + B - 1) / B)), dim3(B), 0,
                            stream, (const T *)f_, (T *)buf_, (uint32_t)nx, (uint32_t)ny, (T)om_);
     else
@@ -365,7 +385,7 @@ template <bool PULL>
 int outer(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, double om, void *stream)
 {
     if (int s = check_pair(f, buf, prec, nx, ny)) return s;
-    if (g_layout == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
+    if (cur_layout() == LBM_LAYOUT_AOS) return fail(LBM_ERR_UNSUPPORTED, "%s", kAosNoHalo);
     if (nx < 4 || ny < 4)
         return fail(LBM_ERR_INVALID_ARGUMENT, "outer ring needs nx,ny >= 4 (got %llux%llu)",
                     (unsigned long long)nx, (unsigned long long)ny);
@@ -421,7 +441,7 @@ template <typename T, bool PULL>
 int sweep_lid_rows(const void *f, void *buf, uint64_t nx, uint64_t ny, double om, double rho, double u, uint64_t y_lo,
                    uint64_t y_hi, int64_t y_goff, uint64_t ny_glob, hipStream_t stream)
 {
-    if (g_arith == lbm::kArithContracted)
+    if (cur_arith() == lbm::kArithContracted)
         return sweep_lid_rows_as<T, PULL, lbm::kArithContracted>(f, buf, nx, ny, om, rho, u, y_lo, y_hi, y_goff, ny_glob, stream);
     return sweep_lid_rows_as<T, PULL, lbm::kArithUnrolled>(f, buf, nx, ny, om, rho, u, y_lo, y_hi, y_goff, ny_glob, stream);
 }
@@ -446,7 +466,7 @@ int lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doubl
             return fail(LBM_ERR_INVALID_ARGUMENT,
                         "slab rows that are not wall rows need a ghost row inside the array");
     }
-    if (g_layout == LBM_LAYOUT_AOS)
+    if (cur_layout() == LBM_LAYOUT_AOS)
         return aos_one_step<PULL, true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, 0, y_goff, ny_glob, stream);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -480,21 +500,36 @@ int fused_wall_split_default()
 }
 int g_fused_wall_split = fused_wall_split_default();
 
+// Tuning and test switches of the multi-step launches: the environment names their start values
+// (read once, when the library is loaded), lbm_set_tuning changes them afterwards.
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+std::atomic<int> g_fused_narrow{env_int("LBM_FUSED_NARROW", 1)};
+std::atomic<int> g_fused_group{env_int("LBM_FUSED_GROUP", -1)};
+std::atomic<int> g_fused_bulk{env_int("LBM_FUSED_BULK", 1)};
+std::atomic<int> g_fused_max_steps{env_int("LBM_FUSED_MAX_STEPS", 0)};
+std::atomic<int> g_fused_min_nodes{env_int("LBM_FUSED_MIN_NODES", 0)};
+
 int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
 // Wavefronts the device holds at once at two per SIMD (the residency of every multi-step kernel):
 // compute units x 4 SIMDs x 2.  2048 on a whole MI355X; a partition (CPX, DPX) has fewer units.
 uint64_t wave_slots()
 {
-    static uint64_t slots[kMaxDevicesForProps] = {};
+    static std::atomic<uint64_t> slots[kMaxDevicesForProps];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesForProps) return 2048;
-    if (slots[dev] == 0) {
+    uint64_t n = slots[dev].load();
+    if (n == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots[dev] = (uint64_t)cus * 8;
+        n = (uint64_t)cus * 8;
+        slots[dev].store(n);
     }
-    return slots[dev];
+    return n;
 }
 
 template <typename T> constexpr int fused_width() { return lbm::kFusedLaneBytes / (int)sizeof(T); }
@@ -522,13 +557,12 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     // lbm_plan_steps gives them) with halos of whole lanes instead of whole 32-byte granules where
     // that makes fewer strips (lbm::fused_halo_lanes): 1024^2 fp32 144 -> 153 GLUPS, fp64 88 -> 91;
     // with the same number of strips the ragged line ends cost 2-4 % (512^2, 768^2), and the cavity
-    // gains nothing (1024^2 push 121 -> 119).  LBM_FUSED_NARROW=0 (read at every launch) keeps the
+    // gains nothing (1024^2 push 121 -> 119).  LBM_FUSED_NARROW=0 (or lbm_set_tuning) keeps the
     // granule, 2 takes narrow halos whatever the strip count.
     const uint64_t W_granule = lbm::kWave - 2 * (k <= 4 ? lbm::fused_halo_lanes<T, V, 4>()
                                                         : lbm::fused_halo_lanes<T, V, lbm::kFusedMaxSteps>());
     const uint64_t W_narrow = lbm::kWave - 2 * lbm::fused_halo_lanes<T, V, lbm::kFusedNarrowSteps, true>();
-    const char *narrow_env = getenv("LBM_FUSED_NARROW");
-    const int narrow_mode = narrow_env ? atoi(narrow_env) : 1;
+    const int narrow_mode = g_fused_narrow.load();
     const bool narrow = k == lbm::kFusedNarrowSteps && !AOS && !LID && V * sizeof(T) == (size_t)lbm::kFusedLaneBytes &&
                         nx * rows < kSmallLatticeNodes && narrow_mode != 0 &&
                         (narrow_mode == 2 || (nx / V + W_narrow - 1) / W_narrow < (nx / V + W_granule - 1) / W_granule);
@@ -585,10 +619,9 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     // the wall cases in every iteration, about a fifth slower than the others (1024^2 fp32, four
     // steps: 44 against 36 us per launch), and a small grid is over when its slowest wavefront is.
     // They get segments short enough to finish with everyone else.
-    // LBM_FUSED_GROUP (read at every launch; tests and tuning): 0 = one wavefront per workgroup
-    // everywhere, 1 = groups wherever the kernel's rings allow them, whatever the lattice size
-    const char *group_env = getenv("LBM_FUSED_GROUP");
-    const int group_mode = group_env ? atoi(group_env) : -1;
+    // LBM_FUSED_GROUP (tests and tuning): 0 = one wavefront per workgroup everywhere, 1 = groups
+    // wherever the kernel's rings allow them, whatever the lattice size
+    const int group_mode = g_fused_group.load();
     uint64_t seg_wall = 0, nsegs_wall = 0;
     if (LID && small_grid && !g_fused_xcd && g_fused_wall_split && group_mode <= 0) {
         const uint64_t extra = (PUSH || AOS) ? 2 * (uint64_t)k : 2 * (uint64_t)(k - 1);
@@ -612,10 +645,8 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     g.wrap_y = wrap_y; g.seg_rows = (uint32_t)seg; g.nstrips = (uint32_t)nstrips; g.nsegs = (uint32_t)nsegs;
     g.y_goff = y_goff; g.ny_glob = ny_glob;
     g.xcd_map = g_fused_xcd;
-    // LBM_FUSED_BULK=0 (read at every launch; tests): every wavefront of a cavity launch runs the code
-    // with the wall cases
-    const char *bulk_env = getenv("LBM_FUSED_BULK");
-    g.bulk_code = bulk_env ? atoi(bulk_env) : 1;
+    // LBM_FUSED_BULK=0 (tests): every wavefront of a cavity launch runs the code with the wall cases
+    g.bulk_code = g_fused_bulk.load();
     g.seg_rows_wall = (uint32_t)seg_wall; g.nsegs_wall = (uint32_t)nsegs_wall;
     const uint64_t nsegs_grid = g.xcd_map ? (nsegs + 7) / 8 * 8 : nsegs;
     const uint64_t nwall = nstrips < 2 ? nstrips : 2;
@@ -635,7 +666,9 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
         if constexpr (KK == lbm::kFusedNarrowSteps && !AOS && !LID && V * sizeof(T) == (size_t)lbm::kFusedLaneBytes) { \
             if (narrow) kern = lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH, true>;                              \
         }                                                                                                        \
-        static std::atomic<bool> lds_allowed[kMaxDevicesForProps];                                               \
+        /* one flag per kernel function and device: the narrow and the granule kernel are two functions */      \
+        static std::atomic<bool> lds_allowed_of[2][kMaxDevicesForProps];                                         \
+        std::atomic<bool> *lds_allowed = lds_allowed_of[narrow ? 1 : 0];                                         \
         if (lds > 64 * 1024 && !lds_allowed[dev].load()) {                                                       \
             const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                      (int)lds);                                                  \
@@ -676,8 +709,8 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
     const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8);
     if constexpr (!LID) {
-        if (g_arith == lbm::kArithRolled) {
-            if (g_layout == LBM_LAYOUT_AOS)
+        if (cur_arith() == lbm::kArithRolled) {
+            if (cur_layout() == LBM_LAYOUT_AOS)
                 return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
             if (narrow)
                 return fail(LBM_ERR_UNSUPPORTED,
@@ -686,16 +719,16 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
             return launch_fused<T, V8, PUSH, false, false, lbm::kArithRolled>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
         }
     }
-    if (g_arith == lbm::kArithContracted) {
+    if (cur_arith() == lbm::kArithContracted) {
         if (narrow)
             return fail(LBM_ERR_UNSUPPORTED,
                         "the contracted arithmetic takes several steps per call only for fp32 rows of an even length >= 4 (nx=%llu)",
                         (unsigned long long)nx);
-        if (g_layout == LBM_LAYOUT_AOS)
+        if (cur_layout() == LBM_LAYOUT_AOS)
             return launch_fused<T, V8, PUSH, LID, true, lbm::kArithContracted>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
         return launch_fused<T, V8, PUSH, LID, false, lbm::kArithContracted>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
     }
-    if (g_layout == LBM_LAYOUT_AOS) {
+    if (cur_layout() == LBM_LAYOUT_AOS) {
         if constexpr (V8 > 1) {
             if (narrow)
                 return launch_fused<T, 1, PUSH, LID, true>(f, buf, nx, ny, om, df, y_lo, y_hi, wrap_y, y_goff, ny_glob, k, stream);
@@ -719,7 +752,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
     const bool supported = lbm_fused_max_steps(prec, nx) > 1;
     // one step of the whole periodic lattice is the one-step sweep's home ground; so is any row
     // length the fused kernels cannot take
-    if (k == 1 && g_layout == LBM_LAYOUT_SOA &&
+    if (k == 1 && cur_layout() == LBM_LAYOUT_SOA &&
         (!supported || (wrap_y && y_lo == 0 && y_hi == ny)))
         return periodic_rows<PULL>(f, buf, prec, nx, ny, om, y_lo, y_hi, wrap_y, stream);
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
@@ -729,7 +762,7 @@ int periodic_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny,
                     k, (unsigned long long)y_lo, (unsigned long long)y_hi, k, (unsigned long long)ny);
     if (!supported)
         return fail(LBM_ERR_UNSUPPORTED, "fused sweeps need rows of at least two nodes%s (nx=%llu)",
-                    g_arith != lbm::kArithUnrolled ? ", and an even number of fp32 nodes with the rolled or contracted arithmetic" : "",
+                    cur_arith() != lbm::kArithUnrolled ? ", and an even number of fp32 nodes with the rolled or contracted arithmetic" : "",
                     (unsigned long long)nx);
     hipStream_t st = (hipStream_t)stream;
     return prec == LBM_F32
@@ -748,7 +781,7 @@ int lid_fused(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, doub
     {
         const bool supported = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
         const bool whole = y_lo == 0 && y_hi == ny && y_goff == 0 && ny_glob == ny;
-        if (k == 1 && g_layout == LBM_LAYOUT_SOA && (!supported || whole))
+        if (k == 1 && cur_layout() == LBM_LAYOUT_SOA && (!supported || whole))
             return lid_rows<PULL>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
     }
     if (int s = check_rows(ny, y_lo, y_hi, false)) return s;
@@ -789,9 +822,9 @@ int aos_one_step(const void *f, void *buf, int prec, uint64_t nx, uint64_t ny, d
     if (nx < 2)
         return fail(LBM_ERR_UNSUPPORTED, "[NY][NX][9] arrays need rows of at least two nodes (nx=%llu)",
                     (unsigned long long)nx);
-    if (!LID && g_arith == lbm::kArithRolled)
+    if (!LID && cur_arith() == lbm::kArithRolled)
         return fail(LBM_ERR_UNSUPPORTED, "the rolled arithmetic is not available on [NY][NX][9] arrays");
-    if (g_arith == lbm::kArithContracted && prec == LBM_F32 && (nx % 2 != 0 || nx < 4))
+    if (cur_arith() == lbm::kArithContracted && prec == LBM_F32 && (nx % 2 != 0 || nx < 4))
         return fail(LBM_ERR_UNSUPPORTED,
                     "the contracted arithmetic on [NY][NX][9] arrays needs fp32 rows of an even length >= 4 (nx=%llu)",
                     (unsigned long long)nx);
@@ -837,10 +870,15 @@ int fill_from_table(void *f_, uint64_t nx, uint64_t ny, uint64_t y_first, const 
     if (e == hipSuccess) {
         const unsigned block = pick_block(nx);
         const dim3 grid = make_grid(nx, block, rows);
-        if (g_layout == LBM_LAYOUT_AOS) {
+        if (cur_layout() == LBM_LAYOUT_AOS) {
             LBM_FOR_BLOCK(block,
                 hipLaunchKernelGGL((lbm::k_fill_rows<T, B, true>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
                                    (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table))
+        } else if (nx % vec_width<T>() == 0) {
+            constexpr int V = vec_width<T>();
+            const dim3 vgrid = make_grid(nx / V, 64, rows);
+            hipLaunchKernelGGL((lbm::k_fill_rows_vec<T, V, 64>), vgrid, dim3(64), 0, stream, (T *)f_, (uint32_t)nx,
+                               (uint32_t)ny, (uint32_t)y_first, (uint32_t)rows, (const T *)d_table);
         } else {
             LBM_FOR_BLOCK(block,
                 hipLaunchKernelGGL((lbm::k_fill_rows<T, B>), grid, dim3(B), 0, stream, (T *)f_, (uint32_t)nx,
@@ -894,7 +932,7 @@ int velocity_t(const void *f, void *out, uint64_t nx, uint64_t ny, uint64_t y_lo
     if (y_lo == y_hi) return LBM_OK;
     const unsigned block = pick_block(nx);
     const dim3 grid = make_grid(nx, block, y_hi - y_lo);
-    if (g_layout == LBM_LAYOUT_AOS) {
+    if (cur_layout() == LBM_LAYOUT_AOS) {
         LBM_FOR_BLOCK(block,
             hipLaunchKernelGGL((lbm::k_velocity<T, WHAT, B, true>), grid, dim3(B), 0, stream, (const T *)f, (T *)out,
                                (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi))
@@ -949,6 +987,12 @@ int static_scratch(uint32_t **out)
     return LBM_OK;
 }
 
+// Rows of workgroups of the reduction's grid (each walks rows gy apart).  16384^2 fp32, 1024 / 2048 /
+// 4096 / 8192 / 16384: 5.8 / 6.0 / 6.15 / 6.2 / 6.2 TB/s (fp64 5.95 ... 6.1) now that a workgroup
+// issues its atomic only if it can raise the key; with one atomic per workgroup 4096 was the best
+// (6.05 TB/s) and 16384 ran at 2.95.
+constexpr uint64_t kMaxSpeedGridRows = 8192;
+
 // `key`: one zeroable word of device scratch (the first of `key_bytes` bytes that are cleared here)
 template <typename T>
 int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint64_t y_lo,
@@ -959,23 +1003,23 @@ int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint6
         constexpr int B = 256;
         constexpr int V = vec_width<T>();
         const uint64_t rows = y_hi - y_lo;
-        if (g_layout == LBM_LAYOUT_AOS) {
+        if (cur_layout() == LBM_LAYOUT_AOS) {
             uint64_t gx = (nx + B - 1) / B;
             if (gx > 64) gx = 64;
-            uint64_t gy = rows < 1024 ? rows : 1024;
+            uint64_t gy = rows < kMaxSpeedGridRows ? rows : kMaxSpeedGridRows;
             hipLaunchKernelGGL((lbm::k_max_speed<T, 1, B, true>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
                                (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
         } else if (nx % V == 0) {
             const uint64_t lanes = nx / V;
             uint64_t gx = (lanes + B - 1) / B;
             if (gx > 64) gx = 64;
-            uint64_t gy = rows < 1024 ? rows : 1024;
+            uint64_t gy = rows < kMaxSpeedGridRows ? rows : kMaxSpeedGridRows;
             hipLaunchKernelGGL((lbm::k_max_speed<T, V, B>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
                                (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
         } else {
             uint64_t gx = (nx + B - 1) / B;
             if (gx > 64) gx = 64;
-            uint64_t gy = rows < 1024 ? rows : 1024;
+            uint64_t gy = rows < kMaxSpeedGridRows ? rows : kMaxSpeedGridRows;
             hipLaunchKernelGGL((lbm::k_max_speed<T, 1, B>), dim3((unsigned)gx, (unsigned)gy), dim3(B), 0, stream,
                                (const T *)f, (uint32_t)nx, (uint32_t)ny, (uint32_t)y_lo, (uint32_t)y_hi, key);
         }
@@ -1016,9 +1060,17 @@ int lbm_set_layout(int layout)
 
 int lbm_get_layout(void) { return g_layout; }
 
+// the arithmetic that UNROLL_LOOPS=true stands for: the default of this process unless that is the rolled one
+int unrolled_arithmetic()
+{
+    const int d = arithmetic_default();
+    return d == lbm::kArithRolled ? lbm::kArithContracted : d;
+}
+
 int lbm_set_unroll_loops(int unrolled)
 {
-    g_arith = unrolled ? lbm::kArithUnrolled : lbm::kArithRolled;
+    if (!unrolled) g_arith = lbm::kArithRolled;
+    else if (g_arith == lbm::kArithRolled) g_arith = unrolled_arithmetic();
     return LBM_OK;
 }
 
@@ -1044,6 +1096,80 @@ int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu)
     g_waves_per_cu = waves_per_cu;
     return LBM_OK;
 }
+
+int lbm_set_tuning(const char *name, int value)
+{
+    if (name == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null tuning name");
+    if (strcmp(name, "fused_narrow") == 0) g_fused_narrow = value;
+    else if (strcmp(name, "fused_group") == 0) g_fused_group = value;
+    else if (strcmp(name, "fused_bulk") == 0) g_fused_bulk = value;
+    else if (strcmp(name, "fused_max_steps") == 0) g_fused_max_steps = value;
+    else if (strcmp(name, "fused_min_nodes") == 0) g_fused_min_nodes = value;
+    else return fail(LBM_ERR_INVALID_ARGUMENT, "unknown tuning switch '%s'", name);
+    return LBM_OK;
+}
+
+int lbm_ctx_create(lbm_ctx **out)
+{
+    if (out == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null context result pointer");
+    lbm_ctx *c = new (std::nothrow) lbm_ctx;
+    if (c == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "out of host memory");
+    c->layout = cur_layout();
+    c->arith = cur_arith();
+    c->threads_x = cur_threads_x();
+    c->waves_per_cu = cur_waves_per_cu();
+    *out = c;
+    return LBM_OK;
+}
+
+int lbm_ctx_destroy(lbm_ctx *ctx)
+{
+    if (ctx != nullptr && t_ctx == ctx) t_ctx = nullptr;
+    delete ctx;
+    return LBM_OK;
+}
+
+int lbm_ctx_make_current(lbm_ctx *ctx)
+{
+    t_ctx = ctx;
+    return LBM_OK;
+}
+
+lbm_ctx *lbm_ctx_get_current(void) { return t_ctx; }
+
+int lbm_ctx_set_layout(lbm_ctx *ctx, int layout)
+{
+    if (ctx == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null context");
+    if (layout != LBM_LAYOUT_SOA && layout != LBM_LAYOUT_AOS)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "unknown layout %d", layout);
+    ctx->layout = layout;
+    return LBM_OK;
+}
+
+int lbm_ctx_set_arithmetic(lbm_ctx *ctx, int arithmetic)
+{
+    if (ctx == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null context");
+    if (arithmetic != LBM_ARITH_UNROLLED && arithmetic != LBM_ARITH_ROLLED && arithmetic != LBM_ARITH_CONTRACTED)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "unknown arithmetic %d", arithmetic);
+    ctx->arith = arithmetic;
+    return LBM_OK;
+}
+
+int lbm_ctx_set_launch_shape(lbm_ctx *ctx, unsigned threads_x, unsigned waves_per_cu)
+{
+    if (ctx == nullptr) return fail(LBM_ERR_INVALID_ARGUMENT, "null context");
+    if (threads_x != 0 && threads_x != 64 && threads_x != 128 && threads_x != 256 && threads_x != 512)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "threads_x must be 0, 64, 128, 256 or 512 (got %u)", threads_x);
+    if (waves_per_cu > 32)
+        return fail(LBM_ERR_INVALID_ARGUMENT, "waves_per_cu must be 0..32 (got %u)", waves_per_cu);
+    ctx->threads_x = threads_x;
+    ctx->waves_per_cu = waves_per_cu;
+    return LBM_OK;
+}
+
+int lbm_ctx_get_layout(const lbm_ctx *ctx) { return ctx ? ctx->layout : -1; }
+
+int lbm_ctx_get_arithmetic(const lbm_ctx *ctx) { return ctx ? ctx->arith : -1; }
 
 int lbm_init_shearwave(void *f, int prec, uint64_t nx, uint64_t ny, double rho_init, double u,
                        uint64_t y_below, uint64_t y_glob, unsigned halo, void *stream)
@@ -1130,8 +1256,8 @@ int lbm_fused_max_steps(int prec, uint64_t nx)
     bool ok = prec == LBM_F32 ? fused_supported<float>(nx) : fused_supported<double>(nx);
     // the rolled and contracted arithmetics are built for 8-byte lanes only, the rolled one not for
     // [NY][NX][9] arrays
-    if (g_arith != lbm::kArithUnrolled && prec == LBM_F32 && (nx % 2 != 0 || nx < 4)) ok = false;
-    if (g_arith == lbm::kArithRolled && g_layout == LBM_LAYOUT_AOS) ok = false;
+    if (cur_arith() != lbm::kArithUnrolled && prec == LBM_F32 && (nx % 2 != 0 || nx < 4)) ok = false;
+    if (cur_arith() == lbm::kArithRolled && cur_layout() == LBM_LAYOUT_AOS) ok = false;
     return ok ? max_fused_steps(prec) : 1;
 }
 int lbm_plan_steps(int prec, uint64_t nx, uint64_t rows, uint64_t remaining)
@@ -1147,9 +1273,8 @@ int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remainin
     // GLUPS, 1024^2 65 -> 95, 2048^2 68 -> 137, 4096^2 86 -> 180, 8192^2 77 -> 231, 16384^2 85 -> 242:
     // fusing pays at every size (small lattices are launch-bound, large ones HBM-bound), so there is
     // no size threshold by default; LBM_FUSED_MIN_NODES sets one.
-    const char *e = getenv("LBM_FUSED_MIN_NODES");
-    const uint64_t min_nodes = e ? strtoull(e, nullptr, 10) : 0ull;
-    if (nx * rows < min_nodes) return 1;
+    const int min_nodes = g_fused_min_nodes.load();
+    if (min_nodes > 0 && nx * rows < (uint64_t)min_nodes) return 1;
     // Large lattices (16384^2, GLUPS at 6/7/8 steps): fp32 strict 325/334/335, contracted 377/410/424
     // (push 372/401/411); fp64 contracted pull 162/167/171, push 159/166/162.  The strict and rolled
     // spellings and the fp64 sweeps take seven (an eighth step gains little or nothing and deepens
@@ -1159,14 +1284,14 @@ int lbm_plan_steps_scene(int prec, uint64_t nx, uint64_t rows, uint64_t remainin
     // kernels that may differ again.
     (void)lid;
     uint64_t dflt = (uint64_t)kmax;
-    if (dflt > 7 && (g_arith != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
+    if (dflt > 7 && (cur_arith() != lbm::kArithContracted || prec == LBM_F64)) dflt = 7;
     // Small lattices (one round of wavefronts or less) are bound by the chain of dependent iterations
     // of a wavefront; more steps lengthen the chain.  fp32 pull, GLUPS at 3/4/5/6/7/8 steps: 512^2
     // 50/56/57/53/52/49, 1024^2 107/128/144/137/136/133, 1536^2 135/160/197/203/212/213, 2048^2
     // 161/196/225/233/253/260.
     if (dflt > (uint64_t)lbm::kFusedNarrowSteps && nx * rows < kSmallLatticeNodes) dflt = (uint64_t)lbm::kFusedNarrowSteps;
-    const char *m = getenv("LBM_FUSED_MAX_STEPS");
-    uint64_t k = m ? strtoull(m, nullptr, 10) : dflt;
+    const int forced = g_fused_max_steps.load();   // LBM_FUSED_MAX_STEPS / lbm_set_tuning
+    uint64_t k = forced > 0 ? (uint64_t)forced : dflt;
     if (k < 1) k = 1;
     if (k > (uint64_t)kmax) k = (uint64_t)kmax;
     // The run is cut into the fewest launches of at most k steps, and those launches are made as

@@ -1044,6 +1044,29 @@ k_fill_rows(T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_first, uint3
     }
 }
 
+// The same for [9][NY][NX] rows that are whole 16-byte vectors long: a lane broadcasts the row's
+// value into one non-temporal 128-bit store per population, a wavefront fills 1 KiB per store
+// (16384^2: fp32 6.3 TB/s against 6.1, fp64 5.85 against 5.73).
+template <typename T, int V, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_fill_rows_vec(T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_first, uint32_t rows,
+                const T *__restrict__ table)
+{
+    const uint32_t v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= nx / V) return;
+    const size_t plane = (size_t)ny * nx;
+    for (uint32_t r = blockIdx.y; r < rows; r += gridDim.y) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const T t = table[q * rows + r];
+            T vec[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) vec[i] = t;
+            store_a<T, V>(rowp(f, plane, q, y_first + r, nx) + (size_t)v * V, vec);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Output path.  WHAT: 0 = ux,uy planes (compute_velocities, io.cpp:136-174), 1 = |u| plane
 // (io.cpp:236-238).
@@ -1124,7 +1147,9 @@ k_max_speed(const T *__restrict__ f, uint32_t nx, uint32_t ny, uint32_t y_lo, ui
         uint32_t m = wave_best[0];
 #pragma unroll
         for (int w = 1; w < BLOCK / kWave; ++w) m = (wave_best[w] > m) ? wave_best[w] : m;
-        if (m != 0) atomicMax(key, m);
+        // the key only grows, so a value read earlier can only be too small: skipping on it is safe,
+        // and most workgroups then issue no atomic (one per workgroup costs 8 % at 65536 workgroups)
+        if (m != 0 && m > __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(key, m);
     }
 }
 

@@ -8,7 +8,8 @@ Scalars that the reference passes as rank-0 device Views (DUI/DFL, global.h:121-
 Python numbers here.  All calls are asynchronous on the tensor's current torch stream unless noted.
 
 `set_layout("aos")` switches every function to the reference's other layout, [NY, NX, 9]
-(COALESCING=false, global.h:40, main.cpp:34-35); the switch is process-wide, like the macro.
+(COALESCING=false, global.h:40, main.cpp:34-35); the switch is process-wide, like the macro.  A
+`Context` carries layout, arithmetic and launch shape with an object instead (`with ctx: ...`).
 
 There is no CPU path: a tensor that is not on a GPU is an error.
 """
@@ -37,7 +38,11 @@ def set_layout(layout: str) -> None:
 
 
 def get_layout() -> str:
-    return _layout
+    """Layout in force for the calling thread: its current Context's, else the process-wide one."""
+    lib = capi.load()
+    cur = lib.lbm_ctx_get_current()
+    code = lib.lbm_ctx_get_layout(cur) if cur else lib.lbm_get_layout()
+    return AOS if code == _LAYOUT_CODES[AOS] else SOA
 
 
 @contextlib.contextmanager
@@ -66,15 +71,70 @@ ARITHMETICS = {"unrolled": 0, "rolled": 1, "contracted": 2}
 
 
 def set_arithmetic(name: str) -> None:
-    """Process-wide spelling of the relaxation: "unrolled" (pull-push.cpp:25-72 as written, default),
-    "rolled" (the reference's UNROLL_LOOPS=false functions) or "contracted" (explicit fused
-    multiply-adds where the reference's own build flags allow a compiler to fuse)."""
-    capi.call("lbm_set_arithmetic", ARITHMETICS[name])
+    """Process-wide spelling of the relaxation: "contracted" (the default: explicit fused
+    multiply-adds where the reference's own build flags allow a compiler to fuse), "unrolled" =
+    "strict" (pull-push.cpp:25-72 with every operation rounded where the text puts it) or "rolled"
+    (the reference's UNROLL_LOOPS=false functions)."""
+    capi.call("lbm_set_arithmetic", ARITHMETICS["unrolled" if name == "strict" else name])
 
 
 def get_arithmetic() -> str:
-    v = int(capi.load().lbm_get_arithmetic())
+    """Arithmetic in force for the calling thread: its current Context's, else the process-wide one."""
+    lib = capi.load()
+    cur = lib.lbm_ctx_get_current()
+    v = int(lib.lbm_ctx_get_arithmetic(cur) if cur else lib.lbm_get_arithmetic())
     return [k for k, x in ARITHMETICS.items() if x == v][0]
+
+
+class Context:
+    """Settings that travel with an object instead of with the process (lbm_ctx of the C ABI):
+    layout, arithmetic and launch shape.  Unspecified settings are copied from those in force where
+    the context is made.  `with ctx:` makes it current for the calling thread for the block, so that
+    every operator called inside runs under its settings whatever the process-wide ones are; blocks
+    nest."""
+
+    def __init__(self, layout=None, arithmetic=None, threads_x=None, waves_per_cu=None):
+        h = C.c_void_p()
+        capi.call("lbm_ctx_create", C.byref(h))
+        self._h = h
+        self._before = []
+        if layout is not None:
+            if layout not in _LAYOUT_CODES:
+                raise ValueError(f"layout must be 'soa' or 'aos', got {layout!r}")
+            capi.call("lbm_ctx_set_layout", h, _LAYOUT_CODES[layout])
+        if arithmetic is not None:
+            capi.call("lbm_ctx_set_arithmetic", h, ARITHMETICS["unrolled" if arithmetic == "strict" else arithmetic])
+        if threads_x is not None or waves_per_cu is not None:
+            capi.call("lbm_ctx_set_launch_shape", h, int(threads_x or 0), int(waves_per_cu or 0))
+
+    @property
+    def layout(self) -> str:
+        return AOS if capi.load().lbm_ctx_get_layout(self._h) == _LAYOUT_CODES[AOS] else SOA
+
+    @property
+    def arithmetic(self) -> str:
+        v = int(capi.load().lbm_ctx_get_arithmetic(self._h))
+        return [k for k, x in ARITHMETICS.items() if x == v][0]
+
+    def __enter__(self):
+        self._before.append(capi.load().lbm_ctx_get_current())
+        capi.call("lbm_ctx_make_current", self._h)
+        return self
+
+    def __exit__(self, *exc):
+        capi.call("lbm_ctx_make_current", C.c_void_p(self._before.pop()))
+        return False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and capi is not None:
+            try:
+                lib = capi.load()
+                if lib.lbm_ctx_get_current() == h.value:
+                    lib.lbm_ctx_make_current(None)
+                lib.lbm_ctx_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
 
 
 @contextlib.contextmanager
@@ -99,9 +159,25 @@ def unroll_loops(unrolled: bool):
         set_unroll_loops(before)
 
 
+_TUNING_DEFAULTS = {"fused_narrow": 1, "fused_group": -1, "fused_bulk": 1, "fused_max_steps": 0, "fused_min_nodes": 0}
+
+
+@contextlib.contextmanager
+def tuning(name: str, value: int):
+    """`with ops.tuning("fused_group", 1): ...` -- one of the library's tuning / test switches
+    (lbm_set_tuning) for a block; the built-in value afterwards."""
+    if name not in _TUNING_DEFAULTS:
+        raise ValueError(f"unknown tuning switch {name!r}")
+    capi.call("lbm_set_tuning", name.encode(), int(value))
+    try:
+        yield
+    finally:
+        capi.call("lbm_set_tuning", name.encode(), _TUNING_DEFAULTS[name])
+
+
 def population_shape(nx: int, ny: int):
     """Shape of a population tensor of an nx x ny lattice in the current layout."""
-    return (ny, nx, Q) if _layout == AOS else (Q, ny, nx)
+    return (ny, nx, Q) if get_layout() == AOS else (Q, ny, nx)
 
 
 def _prec(t: torch.Tensor) -> int:
@@ -118,7 +194,7 @@ def _check_f(f: torch.Tensor, name: str = "f"):
     if not f.is_cuda:
         raise RuntimeError(
             f"{name} lives on {f.device}: the lattice kernels are HIP-only (gfx950); there is no CPU path")
-    if _layout == AOS:
+    if get_layout() == AOS:
         if f.dim() != 3 or f.shape[2] != Q or not f.is_contiguous():
             raise ValueError(f"{name} must be a contiguous [NY, NX, 9] tensor (layout 'aos'), got {tuple(f.shape)}")
         return int(f.shape[1]), int(f.shape[0])

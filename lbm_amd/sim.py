@@ -37,14 +37,17 @@ class Simulation:
     scheme: "pull" or "push".  The reference's lid scene always pushes (main.cpp:72-74); here
             scheme="pull" with scene="lid" selects the pull form of the same boundary conditions.
 
-    The populations are allocated in the layout that is current when the object is made
-    (ops.set_layout: [9, NY, NX], or [NY, NX, 9] for the reference's COALESCING=false); the layout
-    must stay the same for as long as the object is used.
+    layout, arithmetic: "soa" / "aos" and "contracted" / "strict" / "rolled"; None takes what is in force
+    where the object is made (ops.set_layout, ops.set_arithmetic, or an enclosing ops.Context).  The
+    object keeps its settings in a context of its own (self.ctx) and runs every call under it, so
+    simulations with different settings can be interleaved in one process and later changes of the
+    process-wide settings do not reach it.
     """
 
     def __init__(self, nx: int, ny: int, scene: str = SHEAR_WAVE, scheme: str = "pull",
                  dtype: torch.dtype = torch.float32, omega: float = 0.5, rho: float = 1.0,
-                 u: float = 0.1, device="cuda:0"):
+                 u: float = 0.1, device="cuda:0", layout: Optional[str] = None,
+                 arithmetic: Optional[str] = None):
         if scene not in (SHEAR_WAVE, LID_DRIVEN):
             raise ValueError(f"unknown scene {scene!r}")
         if scheme not in ("pull", "push"):
@@ -55,23 +58,37 @@ class Simulation:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("Simulation needs a HIP device; there is no CPU path")
-        self.f = torch.empty(ops.population_shape(self.nx, self.ny), dtype=dtype, device=self.device)
-        self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
+        self.ctx = ops.Context(layout=layout, arithmetic=arithmetic)
         self.t = 0
         self.launches = 0   # sweep launches so far (a launch advances 1..8 steps)
         self.launch_steps = []   # steps taken by each of the most recent launches (bounded)
         self._vel: Optional[torch.Tensor] = None
         self._mag: Optional[torch.Tensor] = None
-        if scene == LID_DRIVEN:
-            ops.init_rest(self.f, self.rho)
-        else:
-            ops.init_shearwave(self.f, self.rho, self.u, 0, self.ny)
+        with self.ctx:
+            self.f = torch.empty(ops.population_shape(self.nx, self.ny), dtype=dtype, device=self.device)
+            self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
+            if scene == LID_DRIVEN:
+                ops.init_rest(self.f, self.rho)
+            else:
+                ops.init_shearwave(self.f, self.rho, self.u, 0, self.ny)
 
     # -- n iterations of {one collide+stream sweep, handle swap} (main.cpp:71-84).  Lattices that
     #    stream from HBM take up to `max_fuse` iterations per launch (same result, one pass over
     #    memory); max_fuse=1 forces one launch per iteration.
     def step(self, n: int = 1, max_fuse: Optional[int] = None) -> None:
-        n = int(n)
+        with self.ctx:
+            self._step(int(n), max_fuse)
+
+    def plan(self, n: int) -> list:
+        """Steps per launch that step(n) will take, in order."""
+        out, n = [], int(n)
+        with self.ctx:
+            while n > 0:
+                out.append(ops.plan_steps(self.f, self.ny, n, lid=self.scene == LID_DRIVEN))
+                n -= out[-1]
+        return out
+
+    def _step(self, n: int, max_fuse: Optional[int]) -> None:
         while n > 0:
             k = ops.plan_steps(self.f, self.ny, n, lid=self.scene == LID_DRIVEN)
             if max_fuse is not None:
@@ -100,19 +117,22 @@ class Simulation:
             n -= k
 
     def max_velocity(self) -> float:
-        return ops.max_velocity(self.f)
+        with self.ctx:
+            return ops.max_velocity(self.f)
 
     def velocities(self) -> torch.Tensor:
         """[2, NY, NX] device tensor: ux plane, uy plane."""
         if self._vel is None:
             self._vel = torch.empty((2, self.ny, self.nx), dtype=self.f.dtype, device=self.device)
-        ops.compute_velocities(self._vel, self.f, 0, 0, self.nx, self.ny)
+        with self.ctx:
+            ops.compute_velocities(self._vel, self.f, 0, 0, self.nx, self.ny)
         return self._vel
 
     def velocity_magnitudes(self) -> torch.Tensor:
         if self._mag is None:
             self._mag = torch.empty((self.ny, self.nx), dtype=self.f.dtype, device=self.device)
-        ops.velocity_magnitudes(self._mag, self.f, 0, self.ny)
+        with self.ctx:
+            ops.velocity_magnitudes(self._mag, self.f, 0, self.ny)
         return self._mag
 
     # -- output() of io.cpp:177-294

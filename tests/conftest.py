@@ -12,6 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(4, (os.cpu_count() or 2) // 2))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The library, ./main and bench.py default to the contracted arithmetic.  The suite's reference
+# point is the strict one (bit-identical to the oracle's literal restatement of pull-push.cpp); tests
+# of the other arithmetics select them explicitly.  Set before the library is loaded, inherited by
+# every child process (command-line driver, ranks of the multi-process tests).
+os.environ.setdefault("LBM_ARITHMETIC", "strict")
 
 
 def pytest_configure(config):

@@ -90,3 +90,78 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
     assert max(scratch) == 0, f"{sum(1 for x in scratch if x)} kernel(s) spill to scratch memory"
     assert max(vgprs) <= 256
     assert any("k_fused" in name for name, _ in kernels)
+
+
+def test_default_arithmetic_follows_the_environment():
+    """The suite starts the library with LBM_ARITHMETIC=strict (tests/conftest.py); a process that says
+    nothing gets the contracted arithmetic, and ./main / bench.py / Simulation inherit that."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from lbm_amd import capi; "
+            "print(capi.load().lbm_get_arithmetic(), capi.load().lbm_get_unroll_loops())" % ROOT)
+    for value, want in ((None, "2 1"), ("strict", "0 1"), ("unrolled", "0 1"), ("contracted", "2 1"), ("rolled", "1 0")):
+        env = {k: v for k, v in os.environ.items() if k != "LBM_ARITHMETIC"}
+        if value is not None:
+            env["LBM_ARITHMETIC"] = value
+        out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip()
+        assert out == want, (value, out)
+    lib = capi.load()
+    assert lib.lbm_get_arithmetic() == 0          # this process: strict
+    # UNROLL_LOOPS=false selects the rolled loops, =true returns to the arithmetic the process started with
+    assert lib.lbm_set_unroll_loops(0) == 0 and lib.lbm_get_arithmetic() == 1
+    assert lib.lbm_set_unroll_loops(1) == 0 and lib.lbm_get_arithmetic() == 0
+    assert lib.lbm_set_arithmetic(2) == 0 and lib.lbm_set_unroll_loops(1) == 0 and lib.lbm_get_arithmetic() == 2
+    assert lib.lbm_set_arithmetic(0) == 0
+
+
+def test_contexts_carry_their_own_settings():
+    """lbm_ctx_*: settings start as those in force where the context is made, change independently of
+    the process-wide ones, and are current per host thread."""
+    import threading
+    lib = capi.load()
+    assert lib.lbm_ctx_get_current() is None
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.lbm_ctx_create(C.byref(a)) == 0 and lib.lbm_ctx_create(C.byref(b)) == 0
+    assert lib.lbm_ctx_create(None) == 1
+    assert (lib.lbm_ctx_get_layout(a), lib.lbm_ctx_get_arithmetic(a)) == (lib.lbm_get_layout(), lib.lbm_get_arithmetic())
+    assert lib.lbm_ctx_set_layout(a, 1) == 0 and lib.lbm_ctx_set_arithmetic(a, 2) == 0
+    assert lib.lbm_ctx_set_layout(a, 7) == 1 and lib.lbm_ctx_set_arithmetic(a, 9) == 1
+    assert lib.lbm_ctx_set_launch_shape(a, 100, 1) == 1 and lib.lbm_ctx_set_launch_shape(a, 64, 6) == 0
+    assert lib.lbm_ctx_set_layout(None, 0) == 1 and lib.lbm_ctx_get_layout(None) == -1
+    # the process-wide settings and the other context have not moved
+    assert (lib.lbm_get_layout(), lib.lbm_get_arithmetic()) == (0, 0)
+    assert (lib.lbm_ctx_get_layout(b), lib.lbm_ctx_get_arithmetic(b)) == (0, 0)
+    # a context made while another is current copies that one's settings
+    assert lib.lbm_ctx_make_current(a) == 0 and lib.lbm_ctx_get_current() == a.value
+    c = C.c_void_p()
+    assert lib.lbm_ctx_create(C.byref(c)) == 0
+    assert (lib.lbm_ctx_get_layout(c), lib.lbm_ctx_get_arithmetic(c)) == (1, 2)
+    # what the planner sees follows the current context: eight steps per launch are the contracted
+    # arithmetic's, seven the strict one's (fp32, a large lattice)
+    assert lib.lbm_plan_steps(4, 16384, 16384, 100) == 8
+    seen = {}
+
+    def other_thread():
+        seen["current"] = lib.lbm_ctx_get_current()
+        seen["plan"] = lib.lbm_plan_steps(4, 16384, 16384, 100)
+        lib.lbm_ctx_make_current(b)
+        seen["after"] = lib.lbm_ctx_get_current()
+
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join()
+    assert seen == {"current": None, "plan": 7, "after": b.value}
+    assert lib.lbm_ctx_get_current() == a.value      # this thread's choice is its own
+    assert lib.lbm_ctx_destroy(a) == 0 and lib.lbm_ctx_get_current() is None   # destroying the current one un-currents it
+    assert lib.lbm_plan_steps(4, 16384, 16384, 100) == 7
+    assert lib.lbm_ctx_destroy(b) == 0 and lib.lbm_ctx_destroy(c) == 0 and lib.lbm_ctx_destroy(None) == 0
+
+
+def test_tuning_switches_are_named():
+    lib = capi.load()
+    assert lib.lbm_set_tuning(b"fused_max_steps", 3) == 0
+    assert lib.lbm_plan_steps(4, 16384, 16384, 100) == 3
+    assert lib.lbm_set_tuning(b"fused_max_steps", 0) == 0
+    assert lib.lbm_plan_steps(4, 16384, 16384, 100) == 7
+    assert lib.lbm_set_tuning(b"no_such_switch", 1) == 1 and b"unknown tuning" in lib.lbm_last_error()
+    assert lib.lbm_set_tuning(None, 1) == 1

@@ -171,12 +171,12 @@ def test_extreme_aspect_ratios_fused_equals_one_step(dtype):
 
 
 @pytest.fixture
-def grouped_launches(monkeypatch):
-    """Workgroups of several wavefronts on lattices of any size (the library reads the variable at
-    every launch); without it only lattices of many rounds of wavefronts are launched that way."""
-    monkeypatch.setenv("LBM_FUSED_GROUP", "1")
-    yield
-    monkeypatch.delenv("LBM_FUSED_GROUP", raising=False)
+def grouped_launches():
+    """Workgroups of several wavefronts on lattices of any size; without the switch only lattices of
+    many rounds of wavefronts are launched that way."""
+    from lbm_amd import ops
+    with ops.tuning("fused_group", 1):
+        yield
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -202,32 +202,39 @@ def test_workgroups_of_several_wavefronts(grouped_launches, dtype, scene, scheme
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scene,scheme", [("shear", "pull"), ("shear", "push")])
 @pytest.mark.parametrize("narrow", ["0", "1", "2"])
-def test_five_steps_with_either_halo_width(monkeypatch, dtype, scene, scheme, narrow):
+def test_five_steps_with_either_halo_width(dtype, scene, scheme, narrow):
     """Small periodic lattices take launches of five steps with halos of whole lanes (58 stored lanes
     per strip in fp32, 54 in fp64) where that makes fewer strips, everything else with halos of whole
-    32-byte granules (56 / 48); LBM_FUSED_NARROW=0 never takes narrow halos, 2 always.  Row lengths
-    around the strip widths of both."""
-    monkeypatch.setenv("LBM_FUSED_NARROW", narrow)
+    32-byte granules (56 / 48); the switch fused_narrow = 0 never takes narrow halos, 2 always.  Row
+    lengths around the strip widths of both."""
+    from lbm_amd import ops
     rng = np.random.default_rng(5 + (dtype == np.float64))
-    for nx, ny in [(116, 9), (118, 9), (112, 7), (108, 7), (54, 11), (56, 11), (1024, 40), (1044, 13), (522, 64)]:
-        f = random_state(rng, nx, ny, dtype)
-        want = oracle_steps(ONE_STEP[(scene, scheme)], f, 5, 1.1, dtype)
-        d_f = torch.from_numpy(f).cuda()
-        d_b = torch.full_like(d_f, float("nan"))
-        run_fused(scene, scheme, d_f, d_b, 1.1, 0, ny, 5, ny_glob=ny)
-        assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {nx}x{ny} five steps, narrow={narrow}")
+    with ops.tuning("fused_narrow", int(narrow)):
+        for nx, ny in [(116, 9), (118, 9), (112, 7), (108, 7), (54, 11), (56, 11), (1024, 40), (1044, 13), (522, 64)]:
+            f = random_state(rng, nx, ny, dtype)
+            want = oracle_steps(ONE_STEP[(scene, scheme)], f, 5, 1.1, dtype)
+            d_f = torch.from_numpy(f).cuda()
+            d_b = torch.full_like(d_f, float("nan"))
+            run_fused(scene, scheme, d_f, d_b, 1.1, 0, ny, 5, ny_glob=ny)
+            assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {nx}x{ny} five steps, narrow={narrow}")
+
+
+@pytest.fixture
+def bulk_switch(bulk):
+    from lbm_amd import ops
+    with ops.tuning("fused_bulk", int(bulk)):
+        yield
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scheme", ["pull", "push"])
 @pytest.mark.parametrize("k", [3, 5, 7, 8])
 @pytest.mark.parametrize("bulk", ["0", "1"])
-def test_cavity_with_and_without_the_periodic_code_in_its_bulk(monkeypatch, dtype, scheme, k, bulk):
+def test_cavity_with_and_without_the_periodic_code_in_its_bulk(bulk_switch, dtype, scheme, k, bulk):
     """Cavities wide and high enough to have wavefronts k nodes or more from every wall: those run the
-    periodic sweep's code (LBM_FUSED_BULK=1, the default) or, like everybody else, the code with the
-    wall cases (0).  Both must give the oracle's populations; whole cavities and a row range with a
-    global offset (a slab of a higher cavity)."""
-    monkeypatch.setenv("LBM_FUSED_BULK", bulk)
+    periodic sweep's code (switch fused_bulk = 1, the default) or, like everybody else, the code with
+    the wall cases (0).  Both must give the oracle's populations; whole cavities and a row range with
+    a global offset (a slab of a higher cavity)."""
     rng = np.random.default_rng(3 * k + (dtype == np.float64))
     name = ONE_STEP[("lid", scheme)]
     for nx, ny in [(1536, 300), (700, 420)]:

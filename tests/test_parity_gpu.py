@@ -72,16 +72,16 @@ def test_long_run_1000_steps(dtype, scene, scheme, monkeypatch):
     assert sim.launches == 200   # runs of five steps on a lattice this small
     assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 5")
     # the same run with a size threshold that sends this lattice to the one-step sweeps
-    monkeypatch.setenv("LBM_FUSED_MIN_NODES", "1000000")
-    sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
-    sim.step(1000)
-    assert sim.launches == 1000
-    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, one-step launches")
-    monkeypatch.delenv("LBM_FUSED_MIN_NODES")
-    monkeypatch.setenv("LBM_FUSED_MAX_STEPS", "3")
-    sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
-    sim.step(1000)
-    assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 3")
+    from lbm_amd import ops
+    with ops.tuning("fused_min_nodes", 1000000):
+        sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
+        sim.step(1000)
+        assert sim.launches == 1000
+        assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, one-step launches")
+    with ops.tuning("fused_max_steps", 3):
+        sim = gpu_sim(scene, scheme, nx, ny, dtype, omega)
+        sim.step(1000)
+        assert_bits_equal(sim.f.cpu().numpy(), ref, f"{scene}/{scheme} 1000 steps, fused launches of 3")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
