@@ -449,8 +449,11 @@ int main(int argc, char *argv[])
         return 1;
     }
 
+    SlabRun slab_run;
+    if (nslabs > 1 && !slab_startup(r.o, slab_run, nslabs)) return 1;
+
     const auto start = std::chrono::high_resolution_clock::now();
-    const bool success = nslabs > 1 ? run_simulation_slabs(r, nslabs) : run_simulation(r);
+    const bool success = nslabs > 1 ? run_simulation_slabs(r, slab_run, nslabs) : run_simulation(r);
     // the reference stops its clock without a fence (main.cpp:428); here every kernel has finished
     die_hip(hipDeviceSynchronize(), "sync");
     const auto end = std::chrono::high_resolution_clock::now();
@@ -469,6 +472,7 @@ int main(int argc, char *argv[])
               << o.nx * o.ny * o.steps << " lattice updates in |" << span << "|ns => " << mlups << " MLUPS"
               << std::endl;
     (*r.out) << std::flush;
+    slab_shutdown(slab_run);
     (void)hipFree(r.f);
     (void)hipFree(r.buf);
     if (r.vel) (void)hipFree(r.vel);

@@ -215,3 +215,33 @@ def test_y_slabs_print_what_one_device_prints():
     with orc.arithmetic("contracted"):
         _, s = orc.run("shear", "pull", 512, 300, 401, 1.1, np.float32, out_every=100)
     assert runs[0].stdout == "".join(orc.fmt(v) + "," for v in s)
+
+
+@pytest.mark.gpu
+def test_y_slabs_over_rccl_print_what_one_device_prints():
+    """LBM_SLAB_TRANSPORT=rccl: the exchange as ncclSend / ncclRecv pairs inside one group on the
+    devices' edge streams (one communicator per device, made by the one process).  On one GPU the
+    device is its own peer and every slab's messages go through the communicator to itself, which
+    exercises staging, the pairing of several messages between the same two ranks, and the
+    schedule; the text must be that of the single-slab run, and of the copy transport."""
+    cases = [("-nx", 256, "-ny", 203, "-w", 0.8, "-s", 1001, "-of", 100, "-omv"),
+             ("-nx", 256, "-ny", 203, "-w", 0.8, "-s", 401, "-of", 100, "-omv", "-push"),
+             ("-nx", 96, "-ny", 70, "-w", 1.2, "-s", 201, "-of", 100, "-ovf", "-ld"),
+             ("-nx", 64, "-ny", 61, "-w", 1.0, "-s", 50, "-of", 7, "-ov"),
+             ("-nx", 1024, "-ny", 2048, "-w", 0.5, "-s", 300, "-of", 50, "-omv")]
+    env = dict(os.environ, LBM_SLAB_TRANSPORT="rccl")
+    for args in cases:
+        one = run_main(*args)
+        for n in (2, 3, 7):
+            p = subprocess.run(["./main", *map(str, args), "-gpus", str(n)], cwd=BUILD, capture_output=True, text=True,
+                               timeout=600, env=env)
+            assert p.returncode == 0, p.stderr
+            assert p.stdout == one.stdout, (args, n)
+            assert "RCCL send/recv" in p.stderr.split("\n")[1], p.stderr
+            check_stderr_contract(p.stderr, args[1], args[3], args[7])
+    # the default on one device is the copy transport; an unknown name is refused
+    p = run_main(*cases[0], "-gpus", 2)
+    assert "device-to-device copies" in p.stderr.split("\n")[1]
+    bad = subprocess.run(["./main", *map(str, cases[0]), "-gpus", "2"], cwd=BUILD, capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, LBM_SLAB_TRANSPORT="mpi"))
+    assert bad.returncode == 1 and "LBM_SLAB_TRANSPORT" in bad.stderr
