@@ -61,7 +61,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-from .slab import _edge_stream
+from .slab import _edge_stream, ranks_share_device
 
 # populations that move in +x, -x, +y, -y (D2Q9 numbering of global.h:86-93)
 RIGHT_MOVERS = (1, 5, 8)
@@ -230,7 +230,8 @@ class CartSimulation:
         self.overlap = bool(overlap) and self.cuda and (self.world == 1 or self.stream_ordered)
         # the device's one communication stream, shared with the y-slab path: see slab._edge_stream
         # for why every object must not take a fresh stream
-        self._comm = _edge_stream(self.device) if (self.overlap and not self.deep) else None
+        self._comm = (_edge_stream(self.device, high_priority=not ranks_share_device(self.device, self.group))
+                      if (self.overlap and not self.deep) else None)
         if self.deep:
             self.overlap = False
             self._exchange_deep()       # ghost rows of the initial state (and the frame columns again)

@@ -34,6 +34,8 @@ on CPU ranks in tests; the default backend is the HIP operator layer and refuses
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -101,7 +103,7 @@ class HipBackend:
 _EDGE_STREAMS = {}
 
 
-def _edge_stream(device: torch.device) -> "torch.cuda.Stream":
+def _edge_stream(device: torch.device, high_priority: bool = True) -> "torch.cuda.Stream":
     """The one edge/communication stream of a device, shared by every slab on it.
 
     Created once per process and device.  Each new high-priority stream makes the HIP runtime open
@@ -113,12 +115,36 @@ def _edge_stream(device: torch.device) -> "torch.cuda.Stream":
     place of RCCL and no kernel of this package.  The schedule's event graph is acyclic (every wait
     names an event recorded earlier in host order), so slab objects share one high-priority queue
     instead of taking a stream each; slabs that share it are ordered behind each other on it.
+
+    high_priority=False: a stream of default priority (what ranks_share_device() asks for: several
+    processes on one device each bring their own queues, and default-priority streams never showed
+    the stall).  The first request for a device decides; later ones get the same stream.
     """
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     s = _EDGE_STREAMS.get(key)
     if s is None:
-        s = _EDGE_STREAMS[key] = torch.cuda.Stream(device, priority=-1)
+        s = _EDGE_STREAMS[key] = torch.cuda.Stream(device, priority=-1 if high_priority else 0)
     return s
+
+
+def ranks_share_device(device: torch.device, group=None) -> bool:
+    """True when another rank of the process group runs on the same physical device as this one
+    (rehearsals of a multi-rank run on fewer GPUs than ranks; a production run has one process per
+    GPU).  Such ranks take their edge stream at default priority: see _edge_stream."""
+    if device.type != "cuda" or not (dist.is_available() and dist.is_initialized()):
+        return False
+    world = dist.get_world_size(group)
+    if world < 2:
+        return False
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    ident = (socket.gethostname(), getattr(props, "uuid", None) and str(props.uuid),
+             getattr(props, "pci_domain_id", None), getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None),
+             None if getattr(props, "pci_bus_id", None) is not None else
+             (os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")), device.index))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, ident, group=group)
+    return everyone.count(ident) > 1
 
 
 class SlabSimulation:
@@ -205,7 +231,10 @@ class SlabSimulation:
             # It also keeps this stream off the hardware queue of the interior stream (HIP gives
             # priority levels their own queues); two streams multiplexed on one hardware queue are
             # processed in submission order and the interior sweep would queue behind the exchange.
-            self.comm_stream = _edge_stream(self.device) if self.overlap else self.compute_stream
+            # Ranks that share a device with another rank (rehearsals) take it at default priority.
+            self.shares_device = ranks_share_device(self.device, self.group) if have_group else False
+            self.comm_stream = (_edge_stream(self.device, high_priority=not self.shares_device)
+                                if self.overlap else self.compute_stream)
             # per step parity (two of each, so that "the previous step's" event can still be waited
             # for after this step's work has been submitted):
             self._edges_done = [torch.cuda.Event(), torch.cuda.Event()]      # edge rows are in buf

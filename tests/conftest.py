@@ -44,13 +44,12 @@ def golden_dir():
 
 
 @pytest.fixture
-def ranks_share_one_gpu(monkeypatch):
+def ranks_share_one_gpu():
     """For tests that start several ranks on cuda:0 (RCCL refuses two ranks on one GPU, so these are
-    rehearsals over gloo).  Every process may open GPU_MAX_HW_QUEUES (4) hardware queues per stream
-    priority; four to six ranks plus the test runner itself ask the device for more queues than it
-    has, the scheduler then time-slices them, and a rank whose streams wait on each other's events
-    was seen to make no progress for minutes (one full-suite run in two; never with the ranks alone
-    on the device).  The children started under this fixture inherit a limit of two queues per
-    priority, the setting under which the cross-stream schedule of the slab and Cartesian drivers
-    never stalled.  A production run has one process per GPU and keeps the default."""
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    rehearsals over gloo).  Ranks that find another rank of their group on their device take their
+    edge stream at default priority (lbm_amd.slab.ranks_share_device): a process's high-priority
+    hardware queues were what stalled when it took cross-queue event waits, default-priority
+    streams never did.  The children run with the HIP runtime's own queue limit; every rank arms a
+    watchdog that prints its stacks and exits, so a stall would fail one test with its location
+    instead of hanging the suite."""
+    yield
