@@ -236,13 +236,15 @@ class CartSimulation:
             self.overlap = False
             self._exchange_deep()       # ghost rows of the initial state (and the frame columns again)
 
-    def _planned_depth(self, dtype, nx_min: int, ny_min: int, lid: bool = False) -> int:
+    def _planned_depth(self, dtype, nx_min: int, ny_min: int, lid: bool = False, framed_x: bool = True) -> int:
         """Steps per launch for the smallest block of the grid, 1 if the multi-step sweeps do not
-        take it.  Every block of the grid is at most one node wider; the row length is made even."""
+        take it.  Every block of the grid is at most one node wider; the row length is made even.
+        framed_x=False: the block has no neighbour along x (a cavity on a 1 x N grid of ranks), so
+        its rows get neither frames nor the extra column and keep the cavity's own length."""
         depth = 1
         for _ in range(2):      # the row length depends on the depth: settle in two rounds
-            w = nx_min + 2 * depth
-            probe = torch.empty((9, 1, w + w % 2), dtype=dtype, device=self.device)
+            w = nx_min + (2 * depth if framed_x else 0)
+            probe = torch.empty((9, 1, w + (w % 2 if framed_x else 0)), dtype=dtype, device=self.device)
             planned = int(self.backend.plan_steps(probe, ny_min, 1 << 30, lid) if lid
                           else self.backend.plan_steps(probe, ny_min, 1 << 30))
             depth = max(1, min(planned, nx_min, ny_min))
@@ -261,7 +263,7 @@ class CartSimulation:
         self.upper = self._rank_at(cx, cy + 1) if cy < self.dims[1] - 1 else None
         nx_min, ny_min = self.nx_glob // self.dims[0], self.ny_glob // self.dims[1]
         if halo is None:
-            halo = self._planned_depth(dtype, nx_min, ny_min, lid=True)
+            halo = self._planned_depth(dtype, nx_min, ny_min, lid=True, framed_x=self.dims[0] > 1)
         self.G = G = int(halo)
         if G < 1:
             raise ValueError(f"halo depth must be positive (got {halo})")

@@ -949,15 +949,24 @@ int velocity_t(const void *f, void *out, uint64_t nx, uint64_t ny, uint64_t y_lo
 // before it returns, so one thread never has two reductions in flight on a line, and two threads
 // never share one.  (lbm_max_velocity_dev needs no scratch: the result word itself is the key.)
 constexpr int kMaxDevices = 64;
-thread_local uint32_t *t_key[kMaxDevices] = {};
+// freed when the host thread ends (a pool of short-lived threads must not leave a line per thread behind)
+struct KeyLines {
+    uint32_t *line[kMaxDevices] = {};
+    ~KeyLines()
+    {
+        for (uint32_t *p : line)
+            if (p != nullptr) (void)hipFree(p);   // any device may be current: hipFree finds the owner
+    }
+};
+thread_local KeyLines t_key;
 
 int key_scratch(uint32_t **out)
 {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(LBM_ERR_NO_DEVICE, "device ordinal %d out of range", dev);
-    if (t_key[dev] == nullptr) HIP_TRY(hipMalloc((void **)&t_key[dev], 256));
-    *out = t_key[dev];
+    if (t_key.line[dev] == nullptr) HIP_TRY(hipMalloc((void **)&t_key.line[dev], 256));
+    *out = t_key.line[dev];
     return LBM_OK;
 }
 
