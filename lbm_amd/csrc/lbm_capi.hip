@@ -512,6 +512,7 @@ std::atomic<int> g_fused_group{env_int("LBM_FUSED_GROUP", -1)};
 std::atomic<int> g_fused_bulk{env_int("LBM_FUSED_BULK", 1)};
 std::atomic<int> g_fused_max_steps{env_int("LBM_FUSED_MAX_STEPS", 0)};
 std::atomic<int> g_fused_min_nodes{env_int("LBM_FUSED_MIN_NODES", 0)};
+std::atomic<int> g_fused_lane_nodes{env_int("LBM_FUSED_LANE_NODES", 0)};
 
 int max_fused_steps(int /*prec*/) { return lbm::kFusedMaxSteps; }
 
@@ -707,7 +708,9 @@ int sweep_fused(const void *f_, void *buf_, uint64_t nx, uint64_t ny, double om_
     const T rho = (T)rho_, u = (T)u_;
     const T df = LID ? rho * u / (T)6. : (T)0.;   // pull-push.cpp:516-518
     constexpr int V8 = fused_width<T>();   // eight bytes of a row per lane
-    const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8);
+    // one node per lane: fp32 rows that cannot be cut into 8-byte lanes, or the tuning switch fused_lane_nodes = 1
+    const bool narrow = V8 > 1 && (nx % V8 != 0 || nx < 2 * V8 ||
+                                   (g_fused_lane_nodes.load() == 1 && cur_arith() == lbm::kArithUnrolled));
     if constexpr (!LID) {
         if (cur_arith() == lbm::kArithRolled) {
             if (cur_layout() == LBM_LAYOUT_AOS)
@@ -1114,6 +1117,7 @@ int lbm_set_tuning(const char *name, int value)
     else if (strcmp(name, "fused_bulk") == 0) g_fused_bulk = value;
     else if (strcmp(name, "fused_max_steps") == 0) g_fused_max_steps = value;
     else if (strcmp(name, "fused_min_nodes") == 0) g_fused_min_nodes = value;
+    else if (strcmp(name, "fused_lane_nodes") == 0) g_fused_lane_nodes = value;
     else return fail(LBM_ERR_INVALID_ARGUMENT, "unknown tuning switch '%s'", name);
     return LBM_OK;
 }

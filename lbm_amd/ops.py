@@ -159,7 +159,8 @@ def unroll_loops(unrolled: bool):
         set_unroll_loops(before)
 
 
-_TUNING_DEFAULTS = {"fused_narrow": 1, "fused_group": -1, "fused_bulk": 1, "fused_max_steps": 0, "fused_min_nodes": 0}
+_TUNING_DEFAULTS = {"fused_narrow": 1, "fused_group": -1, "fused_bulk": 1, "fused_max_steps": 0, "fused_min_nodes": 0,
+                    "fused_lane_nodes": 0}
 
 
 @contextlib.contextmanager

@@ -246,7 +246,7 @@ static void slab_fetch_output(Run &r, SlabRun &sr)
         return;
     }
     const size_t plane = (size_t)o.nx * o.ny;
-    r.host.resize(o.output == VEL_FIELD ? 2 * plane : plane);
+    r.host.resize(o.output == VEL_FIELD ? 2 * plane : plane);   // page-locked: the slabs' copies run side by side
     for (Slab &s : sr.slabs) {
         die_hip(hipSetDevice(s.device), "hipSetDevice");
         hipStream_t cs = sr.compute[s.device];
