@@ -1,8 +1,8 @@
 #!/bin/bash
 # Numbers for the documents: the five baseline configurations in both arithmetics, the other layouts
-# and spellings, the C++ slab driver.  Output: gpurun_out/r02_matrix.txt
+# and spellings, the C++ slab driver over both transports.  Output: gpurun_out/matrix.txt
 set -u
-OUT=$PWD/gpurun_out/r02_matrix.txt
+OUT=$PWD/gpurun_out/matrix.txt
 : > $OUT
 say() { echo "$*" | tee -a $OUT; }
 cli() { (cd build && timeout -k 10 300 ./main "$@" 2>&1 >/dev/null | tail -n 4 | tr '\n' ' ' | sed 's/time loop only (without allocation and initialisation)/loop/; s/GB.s algorithmic.*peak//') >> $OUT; echo >> $OUT; }
@@ -19,9 +19,13 @@ for ar in unrolled contracted; do
   for i in 1 2 3; do cli -nx 16384 -ny 16384 -s 100 -of 0 --shear-wave-decay; done
   cli -nx 16384 -ny 16384 -s 1000 -of 0 --shear-wave-decay
   cli -nx 16384 -ny 16384 -s 1000 -of 0 --shear-wave-decay -push
-  say "cfg3 through -gpus 2 / 4 (slabs on one device)"
-  cli -nx 16384 -ny 16384 -s 100 -of 0 --shear-wave-decay -gpus 2
-  cli -nx 16384 -ny 16384 -s 100 -of 0 --shear-wave-decay -gpus 4
+  say "cfg3 through -gpus 2 / 4 (slabs on one device): peer copies, then RCCL send/recv"
+  for tr in peer rccl; do
+    export LBM_SLAB_TRANSPORT=$tr
+    cli -nx 16384 -ny 16384 -s 100 -of 0 --shear-wave-decay -gpus 2
+    cli -nx 16384 -ny 16384 -s 100 -of 0 --shear-wave-decay -gpus 4
+  done
+  unset LBM_SLAB_TRANSPORT
   unset LBM_ARITHMETIC
   say "cfg4  lid-driven cavity 16384^2 fp64, pull and push (bench.py)"
   bench --scene lid --precision fp64 --scheme pull --arithmetic $ar

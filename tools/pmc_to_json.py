@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merge the summary of one tools/r02_profile_bench.sh run into profiles/pmc_traffic.json.
+"""Merge the summary of one tools/profile_bench.sh run into profiles/pmc_traffic.json.
 
 usage: pmc_to_json.py gpurun_out/prof_TAG NX NY ROUND_TAG
 Every lbm::k_fused<T, V, K, PUSH, LID, AOS, ARITH[, NARROW]> kernel of the summary becomes one entry keyed the way

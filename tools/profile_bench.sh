@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes of the driver's own bench command (GPU box); each pass is its own run.
-# usage: r02_profile_bench.sh TAG [bench.py arguments...]
+# usage: profile_bench.sh TAG [bench.py arguments...]
 set -u
 export TMPDIR=/tmp
 TAG=$1; shift
