@@ -385,7 +385,8 @@ def main():
             workload += f", {world} y-slabs of {nx}x{ny_loc}"
         if baseline_shape or args.strong:
             if world == 1:
-                workload += " (BASELINE configs[2])" if (args.scene, args.scheme, args.precision) == ("shear", "pull", "fp32") else ""
+                if (args.scene, args.scheme, args.precision, args.layout, args.rolled) == ("shear", "pull", "fp32", "soa", False):
+                    workload += " (BASELINE configs[2])"
             else:
                 workload += (" (BASELINE configs[4], strong scaling: 32768x32768 over the GPUs)" if strong else
                              " (BASELINE configs[4], weak scaling: a 32768x4096 slab per GPU)")

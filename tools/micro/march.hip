@@ -37,7 +37,7 @@ __device__ __forceinline__ void st(float *row, uint32_t bytes, uint32_t off, typ
 }
 
 template <int LB, int RB>
-__global__ void __launch_bounds__(256) k_march(const float *__restrict__ a, float *__restrict__ b, const Geom g)
+__global__ void __launch_bounds__(1024) k_march(const float *__restrict__ a, float *__restrict__ b, const Geom g)
 {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
     const uint32_t block = blockIdx.x * (blockDim.x / 64) + wave;
