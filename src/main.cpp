@@ -12,6 +12,8 @@
 // All lattice arithmetic runs in the gfx950 kernels; the host only parses, launches and prints.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cstdint>
@@ -206,17 +208,22 @@ static bool write_block(std::ostream &os, const FLT *a, UINT nx, UINT ny, bool c
         for (UINT i = 0; i < nx * ny; ++i)
             if (a[i] != a[i]) { stop = i; break; }
     const UINT full_rows = stop / nx;          // rows printed whole
-    // Formatting is the expensive part of an output step (a million "%g" per 1024^2 frame): rows
-    // are formatted by a few host threads into per-chunk strings and written in order.
+    // Formatting is the expensive part of an output step (a million numbers per 1024^2 frame): rows
+    // are formatted in chunks by a few host threads that take the next chunk as they finish one, and
+    // this thread writes the chunks in order as they become ready -- formatting and writing overlap.
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
-    if ((UINT)nthreads > full_rows) nthreads = full_rows ? (unsigned)full_rows : 1;
-    std::vector<std::string> chunks(nthreads);
-    auto format_rows = [&](unsigned t) {
-        const UINT y0 = full_rows * t / nthreads, y1 = full_rows * (t + 1) / nthreads;
-        std::string &out = chunks[t];
-        out.reserve((size_t)(y1 - y0) * nx * 10);
+    const UINT rows_per_chunk = std::max<UINT>(1, std::min<UINT>(64, (full_rows + 4 * nthreads - 1) / (4 * nthreads)));
+    const UINT nchunks = (full_rows + rows_per_chunk - 1) / rows_per_chunk;
+    std::vector<std::string> chunks(nchunks);
+    std::vector<std::atomic<int>> ready(nchunks);
+    for (auto &r : ready) r.store(0, std::memory_order_relaxed);
+    std::atomic<UINT> next{0};
+    auto format_chunk = [&](UINT c) {
+        const UINT y0 = c * rows_per_chunk, y1 = std::min(full_rows, y0 + rows_per_chunk);
+        std::string &out = chunks[c];
+        out.reserve((size_t)(y1 - y0) * nx * 12);
         char tmp[64];
         for (UINT y = y0; y < y1; ++y) {
             for (UINT x = 0; x < nx; ++x) {
@@ -225,16 +232,26 @@ static bool write_block(std::ostream &os, const FLT *a, UINT nx, UINT ny, bool c
             }
             out.push_back('\n');
         }
+        ready[c].store(1, std::memory_order_release);
     };
-    if (nthreads > 1) {
+    auto worker = [&]() {
+        for (UINT c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) format_chunk(c);
+    };
+    if (nthreads > 1 && nchunks > 1) {
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(format_rows, t);
-        format_rows(0);
+        for (unsigned t = 0; t + 1 < nthreads && t < nchunks; ++t) pool.emplace_back(worker);
+        for (UINT c = 0; c < nchunks; ++c) {
+            while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+            os.write(chunks[c].data(), (std::streamsize)chunks[c].size());
+            std::string().swap(chunks[c]);
+        }
         for (auto &th : pool) th.join();
     } else {
-        format_rows(0);
+        for (UINT c = 0; c < nchunks; ++c) {
+            format_chunk(c);
+            os.write(chunks[c].data(), (std::streamsize)chunks[c].size());
+        }
     }
-    for (const std::string &c : chunks) os << c;
     if (stop < nx * ny) {
         // the row that holds the NaN: what precedes it is printed, then the run ends (io.cpp:239-243)
         std::string line;
