@@ -419,6 +419,7 @@ static bool run_simulation(Run &r)
 }
 
 #include "slabs.h"
+#include "cart.h"
 
 int main(int argc, char *argv[])
 {
@@ -490,11 +491,41 @@ int main(int argc, char *argv[])
         return 1;
     }
 
+    // The reference cuts its lattice in both directions (MPI_Dims_create, main.cpp:103-104).  Here y-slabs are the
+    // default (their exchange overlaps the sweep); LBM_DECOMPOSITION=2d cuts the N blocks of -gpus N into the grid
+    // MPI_Dims_create would choose, LBM_GRID=PXxPY names the grid outright (src/cart.h).
+    UINT grid_x = 0, grid_y = 0;
+    if (const char *e = std::getenv("LBM_GRID")) {
+        unsigned long long gx = 0, gy = 0;
+        if (std::sscanf(e, "%llux%llu", &gx, &gy) != 2 || gx == 0 || gy == 0) {
+            std::cerr << "LBM_GRID must look like 4x2 (blocks along x, blocks along y)" << std::endl;
+            return 1;
+        }
+        grid_x = gx; grid_y = gy;
+    } else if (const char *e = std::getenv("LBM_DECOMPOSITION")) {
+        if (std::strcmp(e, "2d") == 0 || std::strcmp(e, "cart") == 0) {
+            if (nslabs > 1) cart_dims(nslabs, grid_x, grid_y);
+        } else if (std::strcmp(e, "slabs") != 0) {
+            std::cerr << "LBM_DECOMPOSITION must be slabs or 2d" << std::endl;
+            return 1;
+        }
+    }
+    const bool cart = grid_x * grid_y > 1;
+    if (cart && lbm_get_layout() != LBM_LAYOUT_SOA) {
+        std::cerr << "the 2-D decomposition runs on [9][NY][NX] arrays only (COALESCING=true)" << std::endl;
+        return 1;
+    }
     SlabRun slab_run;
-    if (nslabs > 1 && !slab_startup(r.o, slab_run, nslabs)) return 1;
+    CartRun cart_run;
+    if (cart) {
+        if (!cart_startup(cart_run, (unsigned)(grid_x * grid_y))) return 1;
+    } else if (nslabs > 1 && !slab_startup(r.o, slab_run, nslabs)) {
+        return 1;
+    }
 
     const auto start = std::chrono::high_resolution_clock::now();
-    const bool success = nslabs > 1 ? run_simulation_slabs(r, slab_run, nslabs) : run_simulation(r);
+    const bool success = cart ? run_simulation_cart(r, cart_run, grid_x, grid_y)
+                              : (nslabs > 1 ? run_simulation_slabs(r, slab_run, nslabs) : run_simulation(r));
     // the reference stops its clock without a fence (main.cpp:428); here every kernel has finished
     die_hip(hipDeviceSynchronize(), "sync");
     const auto end = std::chrono::high_resolution_clock::now();
