@@ -282,3 +282,33 @@ def test_two_d_grid_of_blocks_prints_what_one_device_prints():
     p = subprocess.run(["./main", "-nx", "64", "-ny", "64", "-s", "10"], cwd=BUILD, capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, LBM_GRID="two by two"))
     assert p.returncode == 1 and "LBM_GRID" in p.stderr
+
+
+@pytest.mark.gpu
+def test_ov_output_stops_at_the_first_nan():
+    """io.cpp:239-243: the -ov output prints values in scan order until it meets a NaN, reports its
+    place on stderr and the run ends with exit code 1.  An unstable cavity (lid at Mach 1.7) provides
+    the NaN; text and place must be those of the oracle's run (strict arithmetic: the suite's default)."""
+    nx, ny, omega, u = 32, 24, 1.95, 1.0
+    p = run_main("-nx", nx, "-ny", ny, "-w", omega, "-u", u, "-s", 200, "-of", 10, "-ov", "-ld", check=False)
+    f, buf = orc.alloc(nx, ny, np.float32), orc.alloc(nx, ny, np.float32)
+    orc.init_rest(f, np.float32(1.0))
+    want, place = "", None
+    for t in range(200):
+        if t % 10 == 0:
+            m = orc.velocity_magnitudes(f)
+            if np.isnan(m).any():
+                ys, xs = np.nonzero(np.isnan(m))
+                y, x = int(ys[0]), int(xs[0])
+                for row in m[:y]:
+                    want += ",".join(orc.fmt(v) for v in row) + "\n"
+                want += "".join(orc.fmt(v) + "," for v in m[y, :x])
+                place = (x, y)
+                break
+            want += "\n".join(",".join(orc.fmt(v) for v in row) for row in m) + "\n#\n"
+        orc.push_lid_driven(f, buf, np.float32(omega), np.float32(1.0), np.float32(u))
+        f, buf = buf, f
+    assert place is not None, "the oracle's run stayed finite: pick other parameters"
+    assert p.returncode == 1
+    assert f"NaN encountered at x={place[0]} y={place[1]}" in p.stderr
+    assert p.stdout == want
