@@ -103,8 +103,10 @@ int lbm_get_arithmetic(void);
 
 /* Optional launch-shape hint, the counterpart of the reference's -tx/-ty MDRange tile
  * (global.h:95-98, pull-push.cpp:249): threads per workgroup along x (64, 128, 256 or 512) and the
- * cap on resident waves per compute unit for the sweep kernels (1..32; the sweeps stream fastest
- * with about 8-12).  0 keeps the built-in choice for that parameter.  Process-wide. */
+ * cap on resident waves per compute unit for the one-step sweep kernels (1..32; the sweeps stream
+ * fastest with about 8-12).  The multi-step sweeps take threads_x as their workgroup width too
+ * (threads_x / 64 wavefronts with adjacent strips per workgroup, at most four, where their rings
+ * leave room for a group).  0 keeps the built-in choice for that parameter.  Process-wide. */
 int lbm_set_launch_shape(unsigned threads_x, unsigned waves_per_cu);
 
 /* Settings that travel with a caller instead of with the process.  The reference fixes layout and

@@ -659,9 +659,16 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
     const bool grouped = nsegs_wall == 0 && !g.xcd_map && (group_mode < 0 ? !small_grid : group_mode > 0);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesForProps) dev = 0;
+    const unsigned hint_tx = cur_threads_x();
+    const unsigned hint_waves = hint_tx == 0 ? 0u : (hint_tx / 64 > (unsigned)lbm::kFusedMaxGroupWaves ? (unsigned)lbm::kFusedMaxGroupWaves : hint_tx / 64);
 #define LBM_FUSED_CASE(KK)                                                                                       \
     case KK: {                                                                                                   \
-        const unsigned nw = grouped ? (unsigned)lbm::fused_group_waves<T, V, KK, PUSH, LID, AOS, ARITH>() : 1u;  \
+        unsigned nw = grouped ? (unsigned)lbm::fused_group_waves<T, V, KK, PUSH, LID, AOS, ARITH>() : 1u;        \
+        /* the launch-shape hint (the reference's -tx tile width): workgroups of threads_x / 64 wavefronts where */ \
+        /* the kernel's rings leave room for a group at all                                                      */ \
+        if (hint_waves != 0 && nsegs_wall == 0 && !g.xcd_map &&                                                   \
+            lbm::fused_group_waves<T, V, KK, PUSH, LID, AOS, ARITH>() > 1)                                        \
+            nw = hint_waves;                                                                                      \
         const unsigned lds = nw * (unsigned)lbm::fused_lds_bytes_per_wave<T, V, KK, PUSH, LID, AOS, ARITH>();    \
         auto kern = lbm::k_fused<T, V, KK, PUSH, LID, AOS, ARITH>;                                               \
         if constexpr (KK == lbm::kFusedNarrowSteps && !AOS && !LID && V * sizeof(T) == (size_t)lbm::kFusedLaneBytes) { \

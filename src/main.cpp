@@ -367,8 +367,8 @@ static bool run_simulation(Run &r)
 
     std::cerr << "running on" << o.nx << "x" << o.ny << std::endl;
 
-    // -tx/-ty are the reference's MDRange tile; here -tx is the workgroup-width hint (kept only
-    // when it names a supported width) and -ty is ignored
+    // -tx/-ty are the reference's MDRange tile; here -tx is the workgroup-width hint of the one-step and
+    // of the multi-step sweeps (kept only when it names a supported width) and -ty is ignored
     if (o.tx == 64 || o.tx == 128 || o.tx == 256) lbm_set_launch_shape((unsigned)o.tx, 0);
 
     if (o.scene == LID_DRIVEN) die_lbm(lbm_init_rest(r.f, kPrec, o.nx, o.ny, o.rho, r.stream), "init_rest");

@@ -200,6 +200,26 @@ def test_workgroups_of_several_wavefronts(grouped_launches, dtype, scene, scheme
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,scheme", list(ONE_STEP))
+@pytest.mark.parametrize("threads_x", [64, 128, 256, 512])
+def test_launch_shape_hint_sets_the_workgroup_width(dtype, scene, scheme, threads_x):
+    """threads_x of the launch shape (the -tx tile width of the command line) is the workgroup width of
+    the multi-step sweeps too: one, two or four wavefronts with adjacent strips.  Same bits in every
+    width, on lattices whose strips do not fill the last workgroup."""
+    from lbm_amd import ops
+    rng = np.random.default_rng(threads_x + (dtype == np.float64))
+    with ops.Context(threads_x=threads_x):
+        for k in (3, 6, 8):
+            for nx, ny in [(724, 33), (1536, 200), (112, 9)]:
+                f = random_state(rng, nx, ny, dtype)
+                want = oracle_steps(ONE_STEP[(scene, scheme)], f, k, 1.1, dtype)
+                d_f = torch.from_numpy(f).cuda()
+                d_b = torch.full_like(d_f, float("nan"))
+                run_fused(scene, scheme, d_f, d_b, 1.1, 0, ny, k, ny_glob=ny)
+                assert_bits_equal(d_b.cpu().numpy(), want, f"{scene} {scheme} {nx}x{ny} k={k} threads_x={threads_x}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("scene,scheme", [("shear", "pull"), ("shear", "push")])
 @pytest.mark.parametrize("narrow", ["0", "1", "2"])
 def test_five_steps_with_either_halo_width(dtype, scene, scheme, narrow):
