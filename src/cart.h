@@ -34,7 +34,8 @@ struct CartBlock {
 
 struct CartRun {
     std::vector<CartBlock> blocks;
-    std::vector<hipStream_t> stream;   // per device
+    std::vector<hipStream_t> stream;   // per block (block i on device i mod ndev)
+    int ndev = 0;
     UINT px = 1, py = 1, G = 1;
     UINT count = 0;                    // blocks of steps run so far (parity of the events)
     FLT *max_host = nullptr;
@@ -85,7 +86,7 @@ static void cart_exchange(CartRun &cr, int which, unsigned p, bool after_sweeps)
     // columns: a sweep writes its whole rows, frame columns included, so a neighbour's columns may only land after it
     for (CartBlock &b : cr.blocks) {
         die_hip(hipSetDevice(b.device), "hipSetDevice");
-        hipStream_t s = cr.stream[b.device];
+        hipStream_t s = cr.stream[&b - cr.blocks.data()];
         CartBlock &left = cart_at(cr, b.cx + cr.px - 1, b.cy), &right = cart_at(cr, b.cx + 1, b.cy);
         if (after_sweeps) {
             die_hip(hipStreamWaitEvent(s, left.swept[p], 0), "wait");
@@ -98,7 +99,7 @@ static void cart_exchange(CartRun &cr, int which, unsigned p, bool after_sweeps)
     // rows over the full width, once the frame columns they carry have arrived
     for (CartBlock &b : cr.blocks) {
         die_hip(hipSetDevice(b.device), "hipSetDevice");
-        hipStream_t s = cr.stream[b.device];
+        hipStream_t s = cr.stream[&b - cr.blocks.data()];
         CartBlock &left = cart_at(cr, b.cx + cr.px - 1, b.cy), &right = cart_at(cr, b.cx + 1, b.cy);
         CartBlock &lower = cart_at(cr, b.cx, b.cy + cr.py - 1), &upper = cart_at(cr, b.cx, b.cy + 1);
         die_hip(hipStreamWaitEvent(s, left.cols[p], 0), "wait");
@@ -118,7 +119,7 @@ static void cart_block(const Run &r, CartRun &cr, int k)
     const UINT G = cr.G;
     for (CartBlock &b : cr.blocks) {
         die_hip(hipSetDevice(b.device), "hipSetDevice");
-        hipStream_t s = cr.stream[b.device];
+        hipStream_t s = cr.stream[&b - cr.blocks.data()];
         // the frame of f: columns from left and right (waited for by this stream's own row phase), rows from below and above
         CartBlock &lower = cart_at(cr, b.cx, b.cy + cr.py - 1), &upper = cart_at(cr, b.cx, b.cy + 1);
         die_hip(hipStreamWaitEvent(s, lower.rows[q], 0), "wait");
@@ -135,10 +136,9 @@ static void cart_block(const Run &r, CartRun &cr, int k)
 
 static void cart_wait_all(CartRun &cr)
 {
-    for (size_t dev = 0; dev < cr.stream.size(); ++dev) {
-        if (!cr.stream[dev]) continue;
-        die_hip(hipSetDevice((int)dev), "hipSetDevice");
-        die_hip(hipStreamSynchronize(cr.stream[dev]), "sync");
+    for (size_t i = 0; i < cr.blocks.size(); ++i) {
+        die_hip(hipSetDevice(cr.blocks[i].device), "hipSetDevice");
+        die_hip(hipStreamSynchronize(cr.stream[i]), "sync");
     }
 }
 
@@ -153,7 +153,7 @@ static void cart_fetch_output(Run &r, CartRun &cr)
         for (size_t i = 0; i < cr.blocks.size(); ++i) {
             CartBlock &b = cr.blocks[i];
             die_hip(hipSetDevice(b.device), "hipSetDevice");
-            hipStream_t s = cr.stream[b.device];
+            hipStream_t s = cr.stream[&b - cr.blocks.data()];
             // the reduction takes whole rows: frame columns hold neighbours' nodes (harmless duplicates); the extra
             // column of an fp32 block holds nothing physical and gets a copy of an owned column first
             if (b.W > b.nx + 2 * G) {
@@ -177,7 +177,7 @@ static void cart_fetch_output(Run &r, CartRun &cr)
     r.host.resize(o.output == VEL_FIELD ? 2 * plane : plane);
     for (CartBlock &b : cr.blocks) {
         die_hip(hipSetDevice(b.device), "hipSetDevice");
-        hipStream_t s = cr.stream[b.device];
+        hipStream_t s = cr.stream[&b - cr.blocks.data()];
         // planar [rows][W] fields of the block's rows; the owned columns go to their place in the global field
         if (o.output == VEL_MAGS) die_lbm(lbm_velocity_magnitudes(b.f, b.vel, kPrec, b.W, b.H, G, G + b.ny, s), "velocity magnitudes");
         else die_lbm(lbm_compute_velocities(b.f, b.vel, kPrec, b.W, b.H, G, G + b.ny, s), "velocities");
@@ -191,17 +191,19 @@ static void cart_fetch_output(Run &r, CartRun &cr)
     cart_wait_all(cr);
 }
 
-// Devices and streams, ahead of the clock like slab_startup.
+// Devices and streams, ahead of the clock like slab_startup.  Every block has a stream of its own, also where
+// several blocks share a device: the schedule's ordering then rests on its events alone, on one GPU as on many.
 static bool cart_startup(CartRun &cr, unsigned nblocks)
 {
     int ndev = 0;
     die_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
     if (ndev < 1) { std::cerr << "no HIP device" << std::endl; return false; }
-    cr.stream.assign((size_t)ndev, nullptr);
+    cr.ndev = ndev;
+    cr.stream.assign((size_t)nblocks, nullptr);
     const int used = ndev < (int)nblocks ? ndev : (int)nblocks;
-    for (int dev = 0; dev < used; ++dev) {
-        die_hip(hipSetDevice(dev), "hipSetDevice");
-        die_hip(hipStreamCreateWithFlags(&cr.stream[dev], hipStreamNonBlocking), "stream");
+    for (unsigned i = 0; i < nblocks; ++i) {
+        die_hip(hipSetDevice((int)(i % (unsigned)ndev)), "hipSetDevice");
+        die_hip(hipStreamCreateWithFlags(&cr.stream[i], hipStreamNonBlocking), "stream");
     }
     // any two devices that hold blocks may be neighbours
     for (int a = 0; a < used; ++a)
@@ -228,7 +230,7 @@ static bool run_simulation_cart(Run &r, CartRun &cr, UINT px, UINT py)
                   << std::endl;
         return false;
     }
-    const int ndev = (int)cr.stream.size();
+    const int ndev = cr.ndev;
     const unsigned nblocks = (unsigned)(px * py);
     cr.px = px;
     cr.py = py;
@@ -268,7 +270,7 @@ static bool run_simulation_cart(Run &r, CartRun &cr, UINT px, UINT py)
     die_hip(hipHostMalloc((void **)&cr.max_host, nblocks * sizeof(FLT), hipHostMallocDefault), "pinned result words");
     for (CartBlock &b : cr.blocks) {
         die_hip(hipSetDevice(b.device), "hipSetDevice");
-        hipStream_t s = cr.stream[b.device];
+        hipStream_t s = cr.stream[&b - cr.blocks.data()];
         const size_t bytes = (size_t)9 * b.W * b.H * sizeof(FLT);
         die_hip(hipMalloc(&b.f, bytes), "allocating f");
         die_hip(hipMalloc(&b.buf, bytes), "allocating buf");
@@ -322,8 +324,18 @@ static bool run_simulation_cart(Run &r, CartRun &cr, UINT px, UINT py)
         die_hip(hipSetDevice(b.device), "hipSetDevice");
         for (void *p : {b.f, b.buf, b.vel, (void *)b.max_dev})
             if (p) (void)hipFree(p);
+        for (int e = 0; e < 2; ++e)
+            for (hipEvent_t ev : {b.swept[e], b.cols[e], b.rows[e]})
+                if (ev) (void)hipEventDestroy(ev);
     }
+    for (size_t i = 0; i < cr.stream.size(); ++i) {
+        die_hip(hipSetDevice((int)(i % (size_t)ndev)), "hipSetDevice");
+        (void)hipStreamDestroy(cr.stream[i]);
+    }
+    cr.stream.clear();
+    cr.blocks.clear();
     (void)hipHostFree(cr.max_host);
+    cr.max_host = nullptr;
     die_hip(hipSetDevice(0), "hipSetDevice");
     return true;
 }
