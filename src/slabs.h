@@ -490,8 +490,13 @@ static bool run_simulation_slabs(Run &r, SlabRun &sr, unsigned nslabs)
         die_hip(hipSetDevice(s.device), "hipSetDevice");
         for (void *p : {s.f, s.buf, s.vel, s.send_lo, s.send_up, s.recv_lo, s.recv_up, (void *)s.max_dev})
             if (p) (void)hipFree(p);
+        for (int e = 0; e < 2; ++e)
+            for (hipEvent_t ev : {s.interior_done[e], s.edges_done[e], s.xfer_done[e]})
+                if (ev) (void)hipEventDestroy(ev);
     }
+    sr.slabs.clear();
     (void)hipHostFree(sr.max_host);
+    sr.max_host = nullptr;
     die_hip(hipSetDevice(0), "hipSetDevice");
     return true;
 }
@@ -502,4 +507,12 @@ static void slab_shutdown(SlabRun &sr)
 {
     for (ncclComm_t c : sr.comm) (void)ncclCommDestroy(c);
     sr.comm.clear();
+    for (size_t dev = 0; dev < sr.compute.size(); ++dev) {
+        if (!sr.compute[dev]) continue;
+        if (hipSetDevice((int)dev) != hipSuccess) continue;
+        (void)hipStreamDestroy(sr.compute[dev]);
+        (void)hipStreamDestroy(sr.edge[dev]);
+    }
+    sr.compute.clear();
+    sr.edge.clear();
 }
