@@ -58,3 +58,6 @@ bench --rolled --scheme push
 say "== odd row lengths"
 bench --nx 22627 --ny-per-gpu 22627 --precision fp64 --arithmetic contracted
 bench --nx 16383 --ny-per-gpu 16384 --arithmetic unrolled
+say "== the device while loaded (clock and power of the box this ran on)"
+(timeout -k 5 60 python bench.py --steps 400 --warmup 10 --no-cpu-baseline --no-parity > /dev/null 2>&1 &
+ sleep 12; timeout 10 rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|power\|mclk" | tr -s ' ' >> $OUT; wait)
