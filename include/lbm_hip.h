@@ -230,6 +230,13 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
  * Returns LBM_ERR_UNSUPPORTED (nothing launched) for rows of a single node; callers then take
  * nsteps one-step sweeps. */
 
+/* Makes the runtime load, on the current device, the code objects of the sweeps that the settings
+ * in force select (layout, arithmetic) for this precision.  HIP otherwise loads a code object at the
+ * first launch of one of its kernels, a few milliseconds that then fall on that launch.  The
+ * reference pays the same inside Kokkos::initialize (main.cpp:412), ahead of its clock (:421).
+ * Optional; launches nothing. */
+int lbm_load_kernels(int prec);
+
 /* Largest nsteps the fused entry points accept for this precision and row length: 8, or 1 when the
  * row length is unsupported. */
 int lbm_fused_max_steps(int prec, uint64_t nx);

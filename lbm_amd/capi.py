@@ -28,6 +28,7 @@ SIGNATURES = {
     "lbm_set_arithmetic": (_int, [_int]),
     "lbm_get_arithmetic": (_int, []),
     "lbm_set_launch_shape": (_int, [_uint, _uint]),
+    "lbm_load_kernels": (_int, [_int]),
     "lbm_ctx_create": (_int, [C.POINTER(_ptr)]),
     "lbm_ctx_destroy": (_int, [_ptr]),
     "lbm_ctx_make_current": (_int, [_ptr]),

@@ -1051,6 +1051,21 @@ int max_velocity_t(const void *f, void *out_dev, uint64_t nx, uint64_t ny, uint6
 }  // namespace
 
 // ============================================================================================
+// One kernel of the family of multi-step sweeps that the settings in force select: asking the runtime
+// for its attributes makes it load the code object the whole family lives in.
+template <typename T>
+static const void *fused_family_member(int arith, bool aos)
+{
+    constexpr int V = fused_width<T>();
+    if (aos) {
+        if (arith == lbm::kArithContracted) return (const void *)lbm::k_fused<T, V, 1, false, false, true, lbm::kArithContracted>;
+        return (const void *)lbm::k_fused<T, V, 1, false, false, true, lbm::kArithUnrolled>;
+    }
+    if (arith == lbm::kArithContracted) return (const void *)lbm::k_fused<T, V, 1, false, false, false, lbm::kArithContracted>;
+    if (arith == lbm::kArithRolled) return (const void *)lbm::k_fused<T, V, 1, false, false, false, lbm::kArithRolled>;
+    return (const void *)lbm::k_fused<T, V, 1, false, false, false, lbm::kArithUnrolled>;
+}
+
 extern "C" {
 
 const char *lbm_status_string(int status)
@@ -1268,6 +1283,24 @@ int lbm_pull_lid_rows(const void *f, void *buf, int prec, uint64_t nx, uint64_t 
                       uint64_t ny_glob, void *stream)
 {
     return lid_rows<true>(f, buf, prec, nx, ny, om, rho_eq, u_lid, y_lo, y_hi, y_goff, ny_glob, stream);
+}
+
+int lbm_load_kernels(int prec)
+{
+    if (prec != LBM_F32 && prec != LBM_F64) return fail(LBM_ERR_INVALID_ARGUMENT, "precision tag must be 4 or 8 (got %d)", prec);
+    const bool aos = cur_layout() == LBM_LAYOUT_AOS;
+    const int arith = cur_arith();
+    const void *members[2] = {
+        prec == LBM_F32 ? fused_family_member<float>(arith, aos) : fused_family_member<double>(arith, aos),
+        // the one-step sweeps, the initialisers and the output kernels share a code object
+        prec == LBM_F32 ? (const void *)lbm::k_max_speed<float, 1, 256> : (const void *)lbm::k_max_speed<double, 1, 256>,
+    };
+    for (const void *k : members) {
+        hipFuncAttributes attr;
+        const hipError_t e = hipFuncGetAttributes(&attr, k);
+        if (e != hipSuccess) return fail(LBM_ERR_HIP, "loading the sweep kernels: %s", hipGetErrorString(e));
+    }
+    return LBM_OK;
 }
 
 int lbm_fused_max_steps(int prec, uint64_t nx)

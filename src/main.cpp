@@ -523,6 +523,10 @@ int main(int argc, char *argv[])
         return 1;
     }
 
+    // single device: the sweeps' code objects are loaded ahead of the clock, where the reference has
+    // Kokkos::initialize (main.cpp:412, :421); the decompositions do it per device in their start-up
+    if (!cart && nslabs <= 1) die_lbm(lbm_load_kernels(kPrec), "loading the kernels");
+
     const auto start = std::chrono::high_resolution_clock::now();
     const bool success = cart ? run_simulation_cart(r, cart_run, grid_x, grid_y)
                               : (nslabs > 1 ? run_simulation_slabs(r, slab_run, nslabs) : run_simulation(r));

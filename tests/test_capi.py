@@ -38,6 +38,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.lbm_init_rest(C.c_void_p(4096), 4, 0, 8, 1.0, None) == 1
     assert lib.lbm_pull_periodic_no_mpi(C.c_void_p(4096), C.c_void_p(4096), 4, 8, 8, 0.5, None) == 1
     assert b"overlap" in lib.lbm_last_error()
+    assert lib.lbm_load_kernels(3) == 1          # bad precision tag: refused before any HIP call
     assert lib.lbm_set_launch_shape(100, 1) == 1
     assert lib.lbm_set_launch_shape(0, 0) == 0
 

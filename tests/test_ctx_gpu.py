@@ -104,3 +104,13 @@ def test_two_host_threads_with_different_contexts():
     for arith in ("strict", "contracted"):
         assert_bits_equal(results[arith], oracle_state(arith, "shear", "pull", nx, ny, steps, omega, np.float32), arith)
     assert not np.array_equal(results["strict"], results["contracted"])
+
+
+def test_kernels_load_ahead_of_the_first_launch():
+    """lbm_load_kernels: every family of sweeps that a combination of settings selects is in the library
+    (a missing instantiation would fail here, not at somebody's first launch)."""
+    from lbm_amd import capi, ops
+    for layout, arith in (("soa", "strict"), ("soa", "contracted"), ("soa", "rolled"), ("aos", "strict"), ("aos", "contracted")):
+        with ops.Context(layout=layout, arithmetic=arith):
+            capi.call("lbm_load_kernels", 4)
+            capi.call("lbm_load_kernels", 8)
