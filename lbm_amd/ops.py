@@ -323,6 +323,14 @@ def fused_max_steps(f) -> int:
     return int(capi.load().lbm_fused_max_steps(_prec(f), nx))
 
 
+def load_kernels(f) -> None:
+    """Load the sweeps' code objects for f's precision and the settings in force onto f's device now
+    instead of at the first launch (lbm_load_kernels)."""
+    _check_f(f)
+    with torch.cuda.device(f.device):
+        capi.call("lbm_load_kernels", _prec(f))
+
+
 def plan_steps(f, rows, remaining, lid: bool = False) -> int:
     """Steps the next launch of the time loop should take (1 .. fused_max_steps, <= remaining);
     lid: the launch is a lid-driven cavity sweep."""

@@ -67,6 +67,7 @@ class Simulation:
         with self.ctx:
             self.f = torch.empty(ops.population_shape(self.nx, self.ny), dtype=dtype, device=self.device)
             self.buf = torch.empty_like(self.f)  # needs no initialisation (main.cpp:206)
+            ops.load_kernels(self.f)
             if scene == LID_DRIVEN:
                 ops.init_rest(self.f, self.rho)
             else:
