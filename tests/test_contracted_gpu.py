@@ -7,7 +7,7 @@ reference's own build flags let a compiler fuse (CMakeLists.txt:18; pull-push.cp
   1e-12 fp64, max-abs on populations);
 * against the decay series the reference's authors recorded (docs/decays.js), whose build contracted;
 * the fp32 reciprocal (hardware estimate + one fused Newton step) equals the correctly rounded
-  quotient for every fp32 value of three binades.
+  quotient for every fp32 value of three binades, the fp64 one for millions of sampled values.
 """
 import json
 import os
@@ -54,6 +54,22 @@ def test_reciprocal_is_correctly_rounded_for_every_fp32_of_three_binades():
         x = x[np.abs(x) > 1e-3]
         got = ops.selftest_reciprocal(torch.from_numpy(x).cuda()).cpu().numpy()
         assert np.array_equal(got, dt(1.0) / x)
+    # fp64 (seven fused operations from the hardware estimate): sixteen million random significands of
+    # one binade, the significands next to a power of two from either side, and far binades
+    bad = 0
+    for _ in range(4):
+        x = 1.0 + rng.random(1 << 22)
+        got = ops.selftest_reciprocal(torch.from_numpy(x).cuda()).cpu().numpy()
+        bad += int((got.view(np.uint64) != (1.0 / x).view(np.uint64)).sum())
+    edge = np.concatenate([np.uint64(0x3FF0000000000000) + np.arange(1 << 16, dtype=np.uint64),
+                           np.uint64(0x3FFFFFFFFFFFFFFF) - np.arange(1 << 16, dtype=np.uint64)]).view(np.float64)
+    got = ops.selftest_reciprocal(torch.from_numpy(edge).cuda()).cpu().numpy()
+    bad += int((got.view(np.uint64) != (1.0 / edge).view(np.uint64)).sum())
+    far = (1.0 + rng.random(1 << 18)) * 2.0 ** rng.integers(-1000, 1000, 1 << 18).astype(np.float64)
+    far = np.concatenate([far, -far])
+    got = ops.selftest_reciprocal(torch.from_numpy(far).cuda()).cpu().numpy()
+    bad += int((got.view(np.uint64) != (1.0 / far).view(np.uint64)).sum())
+    assert bad == 0
     # far binades (scale invariance, spot-checked)
     x = (np.float32(1.0) + rng.random(1 << 16, dtype=np.float32)) * np.float32(2.0) ** rng.integers(-120, 120, 1 << 16).astype(np.float32)
     got = ops.selftest_reciprocal(torch.from_numpy(x).cuda()).cpu().numpy()
