@@ -1,4 +1,4 @@
-"""The C++ a maintainer is told to add to the reference (the ```cpp blocks of INTEGRATION.md) compiles
+"""The C++ a maintainer is told to add to the reference (the ```cpp blocks of the integration guide) compiles
 against include/lbm_hip.h: argument counts and types of every documented call match the header.
 Stand-ins replace what the reference's own headers declare (Dst_t, FLT, the option globals)."""
 import os
