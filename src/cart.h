@@ -204,7 +204,7 @@ static bool cart_startup(CartRun &cr, unsigned nblocks)
     for (unsigned i = 0; i < nblocks; ++i) {
         die_hip(hipSetDevice((int)(i % (unsigned)ndev)), "hipSetDevice");
         die_hip(hipStreamCreateWithFlags(&cr.stream[i], hipStreamNonBlocking), "stream");
-        if (i < (unsigned)ndev) die_lbm(lbm_load_kernels(kPrec), "loading the kernels");
+        if (i < (unsigned)ndev) warm_device(cr.stream[i]);
     }
     // any two devices that hold blocks may be neighbours
     for (int a = 0; a < used; ++a)

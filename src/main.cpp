@@ -355,13 +355,29 @@ static bool emit_output(Run &r)
     return true;
 }
 
+// Start-up work of the current device that belongs ahead of the clock (the reference has Kokkos::initialize
+// there, main.cpp:412 against :421): the sweeps' code objects, which HIP would otherwise load at the first
+// launch, and the runtime's copy queues -- a process's first host-to-device copy of more than a few KB takes
+// 4 ms on a device (the initialisers send a table of per-row values that way), the first copy back likewise
+// (every sample of the outputs is one).
+static void warm_device(hipStream_t stream)
+{
+    die_lbm(lbm_load_kernels(kPrec), "loading the kernels");
+    const size_t bytes = 1 << 20;
+    void *dev = nullptr;
+    die_hip(hipMalloc(&dev, bytes), "start-up probe");
+    std::vector<char> host(bytes, 0);
+    die_hip(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, stream), "start-up probe");
+    die_hip(hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, stream), "start-up probe");
+    die_hip(hipStreamSynchronize(stream), "start-up probe");
+    (void)hipFree(dev);
+}
+
 // run_simulation_single_node of main.cpp:31-89
 static bool run_simulation(Run &r)
 {
     const Options &o = r.o;
     const size_t bytes = (size_t)9 * o.nx * o.ny * sizeof(FLT);
-    // buf (and vel) are allocated by a second host thread while this one allocates f and starts its
-    // initialisation: mapping tens of GB is host-side work (6 ms per 10 GB) that the device need not wait for
     // LBM_TRACE_SETUP=1: where the set-up time goes, on stderr (ahead of the last line)
     const bool trace = std::getenv("LBM_TRACE_SETUP") != nullptr;
     const auto t_setup = std::chrono::high_resolution_clock::now();
@@ -371,20 +387,11 @@ static bool run_simulation(Run &r)
                   << std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t_setup).count()
                   << " us" << std::endl;
     };
-    hipError_t side_status = hipSuccess;
-    std::thread side([&] {
-        side_status = hipSetDevice(0);
-        if (side_status == hipSuccess) side_status = hipMalloc(&r.buf, bytes);
-        mark("buf allocated (second thread)");
-        if (side_status == hipSuccess && (o.output == VEL_MAGS || o.output == VEL_FIELD))
-            side_status = hipMalloc(&r.vel, (size_t)2 * o.nx * o.ny * sizeof(FLT));
-    });
-    const hipError_t f_status = hipMalloc(&r.f, bytes);
-    if (f_status != hipSuccess) {
-        side.join();
-        die_hip(f_status, "allocating f");
-    }
-    mark("f allocated");
+    die_hip(hipMalloc(&r.f, bytes), "allocating f");
+    die_hip(hipMalloc(&r.buf, bytes), "allocating buf");
+    if (o.output == VEL_MAGS || o.output == VEL_FIELD)
+        die_hip(hipMalloc(&r.vel, (size_t)2 * o.nx * o.ny * sizeof(FLT)), "allocating vel");
+    mark("arrays allocated");
 
     std::cerr << "running on" << o.nx << "x" << o.ny << std::endl;
 
@@ -394,10 +401,7 @@ static bool run_simulation(Run &r)
 
     if (o.scene == LID_DRIVEN) die_lbm(lbm_init_rest(r.f, kPrec, o.nx, o.ny, o.rho, r.stream), "init_rest");
     else die_lbm(lbm_init_shearwave(r.f, kPrec, o.nx, o.ny, o.rho, o.u, 0, o.ny, 0, r.stream), "init_shearwave");
-    mark("initialiser launched");
-    side.join();
-    die_hip(side_status, "allocating buf");
-    mark("second thread joined");
+    mark("initial state written");
 
     const auto t0 = std::chrono::high_resolution_clock::now();
     // The reference's loop body is {output if due, one sweep, swap}.  Between two outputs the
@@ -489,16 +493,9 @@ int main(int argc, char *argv[])
         // the device code is loaded at the first launch: one one-element kernel of the library here, still
         // on the start-up side of the clock
         void *probe = nullptr;
-        const size_t probe_bytes = 1 << 20;
-        die_hip(hipMalloc(&probe, probe_bytes), "start-up probe");
+        die_hip(hipMalloc(&probe, 256), "start-up probe");
         die_hip(hipMemset(probe, 0x3f, 256), "start-up probe");
         die_lbm(lbm_selftest_reciprocal(probe, (char *)probe + 128, kPrec, 1, r.stream), "start-up probe");
-        // likewise the copy engines: a process's first host-to-device copy of more than a few KB takes 4 ms
-        // while the runtime sets up its copy queue (the initialisers send a table of per-row values that
-        // way), the first copy back likewise (every sample of the outputs is one)
-        std::vector<char> host(probe_bytes, 0);
-        die_hip(hipMemcpyAsync(probe, host.data(), probe_bytes, hipMemcpyHostToDevice, r.stream), "start-up probe");
-        die_hip(hipMemcpyAsync(host.data(), probe, probe_bytes, hipMemcpyDeviceToHost, r.stream), "start-up probe");
         die_hip(hipStreamSynchronize(r.stream), "start-up probe");
         (void)hipFree(probe);
     }
@@ -555,9 +552,9 @@ int main(int argc, char *argv[])
         return 1;
     }
 
-    // single device: the sweeps' code objects are loaded ahead of the clock, where the reference has
-    // Kokkos::initialize (main.cpp:412, :421); the decompositions do it per device in their start-up
-    if (!cart && nslabs <= 1) die_lbm(lbm_load_kernels(kPrec), "loading the kernels");
+    // single device: code objects and copy queues ahead of the clock; the decompositions do it per device
+    // in their start-up
+    if (!cart && nslabs <= 1) warm_device(r.stream);
 
     const auto start = std::chrono::high_resolution_clock::now();
     const bool success = cart ? run_simulation_cart(r, cart_run, grid_x, grid_y)

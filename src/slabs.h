@@ -288,7 +288,7 @@ static bool slab_startup(const Options &o, SlabRun &sr, unsigned nslabs)
         die_hip(hipStreamCreateWithFlags(&sr.compute[dev], hipStreamNonBlocking), "stream");
         // one high-priority stream per device: the edge sweeps and the exchange are short and everybody waits for them
         die_hip(hipStreamCreateWithPriority(&sr.edge[dev], hipStreamNonBlocking, hi), "stream");
-        die_lbm(lbm_load_kernels(kPrec), "loading the kernels");
+        warm_device(sr.compute[dev]);
     }
     if (sr.rccl) {
         std::vector<int> devs((size_t)ndev_used);
