@@ -601,11 +601,12 @@ int launch_fused(const T *f, T *buf, uint64_t nx, uint64_t ny, T om, T df, uint6
             // Larger grids: the same count, over the lengths at which a wavefront is as efficient
             // as at 128 rows.  16384^2 in 128-row segments is 9.2 rounds, in 118-row ones 9.98:
             // fp32 pull 296 -> 305 GLUPS, push 294 -> 301, cavity push 300 -> 309.
-            // Seven and eight steps have more rows of y halo to amortise: 140 to 186 rows there
+            // Seven and eight steps have more rows of y halo to amortise: 140 to 224 rows there
             // (16384^2 fp32, eight steps, GLUPS at 100/118/140/160/186/223/279/372 rows:
-            // 406/418/420/423/424/423/417/404).
+            // 406/418/420/423/424/423/417/404).  The wider the range, the better the rounds of a slab
+            // come out: 4080 rows of 32768 nodes are 3.72 rounds at 158 rows, 2.86 at 204.
             uint64_t best = ~0ull;
-            for (uint64_t s = (k >= 7 ? 186 : 128); s >= (k >= 7 ? 140u : 96u); --s) {
+            for (uint64_t s = (k >= 7 ? 224 : 128); s >= (k >= 7 ? 140u : 96u); --s) {
                 const uint64_t waves = nstrips * ((rows + s - 1) / s);
                 const uint64_t cost = ((waves + slots - 1) / slots) * (s + extra);
                 if (cost < best) { best = cost; seg = s; }
